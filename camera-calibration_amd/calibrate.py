@@ -1,0 +1,158 @@
+"""Calibrator drop-in for the nonlinear stage (reference: src/calibrate.py:12-282).
+
+`refineCalibrationParameters`, `projectAllPoints`, `_computeReprojectionError`
+and the parameter (de)composition keep the reference's names, argument order
+and return types; the LM loop itself runs on the MI355X through the C-ABI of
+include/calib_lm.h. The DLT / closed-form initialisation
+(`estimateCalibrationParameters`) stays host code (linearcalibrate.py).
+"""
+import operator
+import time
+
+import numpy as np
+
+from . import distortion
+from . import engine
+from . import jacobian
+from . import mathutils as mu
+
+
+class Calibrator:
+    _λinitial = engine.LAMBDA_INITIAL       # src/calibrate.py:13-16
+    _λmin = engine.LAMBDA_MIN
+    _λmax = engine.LAMBDA_MAX
+    _Pt_error_min = engine.PT_ERROR_MIN
+
+    def __init__(self, distortionModel: distortion.DistortionModel, *, dtype="f64", device=0):
+        self._distortionModel = distortionModel
+        self._jac = None
+        self._dtype = dtype
+        self._device = device
+        self.lastTrace = None        # (iters, 5+L) rows of the last refine (see calib_lm.h)
+
+    # ---- full pipeline (host initialisation + device refinement) -------------------------
+    def calibrate(self, allDetections, maxIters):
+        """src/calibrate.py:21-39 -> (sse, Afinal, Wfinal, kFinal)"""
+        Ainitial, Winitial, kInitial = self.estimateCalibrationParameters(allDetections)
+        return self.refineCalibrationParameters(Ainitial, Winitial, kInitial, allDetections,
+                                                maxIters, shouldPrint=True)
+
+    def estimateCalibrationParameters(self, allDetections):
+        """src/calibrate.py:41-58: Zhang's closed-form initialisation, on the host."""
+        from . import linearcalibrate
+        return linearcalibrate.estimateCalibrationParameters(self._distortionModel, allDetections)
+
+    # ---- the hot path --------------------------------------------------------------------
+    def refineCalibrationParameters(self, Ainitial, Winitial, kInitial, allDetections,
+                                    maxIters, shouldPrint=False):
+        """Levenberg-Marquardt over all parameters (src/calibrate.py:117-171).
+
+        Returns (Pt_error, Arefined, Wrefined, kRefined) where Pt_error is, as in the
+        reference, the error evaluated BEFORE the last update."""
+        self._initializeJacobian()
+        maxIters = operator.index(maxIters)
+        Pt = self._composeParameterVector(Ainitial, Winitial, kInitial)
+        offs, sensor, model = engine.packDetections(allDetections)
+        sse, P, iters, trace = self.refinePacked(Pt, offs, sensor, model, maxIters, shouldPrint)
+        Arefined, Wrefined, kRefined = self._decomposeParameterVector(P)
+        return sse, Arefined, Wrefined, kRefined
+
+    def refinePacked(self, P0, viewOffsets, sensorPoints, modelPoints, maxIters, shouldPrint=False):
+        """Same loop on already-stacked correspondences (CSR over views): the form that scales
+        to millions of views. -> (sse, P (K,), iters, trace)"""
+        if maxIters <= 0:
+            raise UnboundLocalError("local variable 'Pt_error' referenced before assignment")
+        eng = engine.RefineEngine(self._distortionModel.modelId, self._dtype, self._device)
+        try:
+            eng.setProblem(viewOffsets, sensorPoints, modelPoints)
+            if not shouldPrint:
+                out = eng.refine(P0, maxIters, self._λinitial, self._λmin, self._λmax,
+                                 self._Pt_error_min)
+            else:
+                out = self._refineVerbose(eng, P0, maxIters)
+        finally:
+            eng.close()
+        self.lastTrace = out[3]
+        return out
+
+    def _refineVerbose(self, eng, P0, maxIters):
+        # one round at a time so that the per-iteration print of src/calibrate.py:158-159
+        # appears while the loop runs, with real elapsed times
+        ts = time.time()
+        eng.lmBegin(P0, maxIters, self._λinitial, self._λmin, self._λmax, self._Pt_error_min)
+        eng.lmRun(1)
+        for it in range(maxIters):
+            eng.lmRun(1)
+            row, itersDone = eng.peekTrace(it)
+            if itersDone > it:
+                error = row[1] if not (row[2] < row[1]) else row[2]     # min(Pt1_error, Pt_error)
+                self._printIterationStats(it, ts, row[5:], error, row[3])
+            if eng.lmDone():
+                break
+        return eng.lmEnd()
+
+    def _initializeJacobian(self):
+        # src/calibrate.py:173-176; instantaneous here (no symbolic differentiation)
+        if self._jac is None:
+            self._jac = jacobian.ProjectionJacobian(self._distortionModel, self._dtype, self._device)
+
+    def _computeReprojectionError(self, P, allDetections):
+        """sum over points of ||sensor - projection||^2 (src/calibrate.py:178-183)"""
+        offs, sensor, model = engine.packDetections(allDetections)
+        eng = engine.RefineEngine(self._distortionModel.modelId, self._dtype, self._device)
+        try:
+            eng.setProblem(offs, sensor, model)
+            return eng.evaluate(np.asarray(P, dtype=np.float64).ravel())["sse"]
+        finally:
+            eng.close()
+
+    def _computeTotalError(self, ydot, y):
+        """src/calibrate.py:185-188"""
+        return np.sum(np.linalg.norm(np.asarray(ydot) - np.asarray(y), axis=1) ** 2)
+
+    def projectAllPoints(self, P, allModelPoints):
+        """(MN,2) projection of every view's model points (src/calibrate.py:190-197)"""
+        offs, model = engine.packModelPoints(allModelPoints)
+        eng = engine.RefineEngine(self._distortionModel.modelId, self._dtype, self._device)
+        try:
+            eng.setProblem(offs, None, model)
+            return eng.evaluate(np.asarray(P, dtype=np.float64).ravel(), wantY=True)["y"]
+        finally:
+            eng.close()
+
+    # ---- parameter vector (host, O(M) per call) ------------------------------------------
+    def _composeParameterVector(self, A, W, k):
+        """P = (α, β, γ, uc, vc, k..., [ρx, ρy, ρz, tx, ty, tz] per view)^T, shape (K,1);
+        rotations as Euler angles in degrees (src/calibrate.py:199-229)."""
+        A = np.asarray(A, dtype=np.float64)
+        W = np.asarray(W, dtype=np.float64).reshape(-1, 4, 4)
+        shared = np.array([A[0, 0], A[1, 1], A[0, 1], A[0, 2], A[1, 2]] + list(k), dtype=np.float64)
+        ext = np.hstack((mu.rotationMatricesToEuler(W[:, :3, :3]), W[:, :3, 3]))
+        return np.concatenate((shared, ext.ravel())).reshape(-1, 1)
+
+    def _decomposeParameterVector(self, P):
+        """-> A (3,3), W list of (4,4), k (|k|,)  (src/calibrate.py:231-267)"""
+        P = np.asarray(P, dtype=np.float64).ravel()
+        numDistortionParameters = len(self._distortionModel.getDistortionSymbols())
+        start = 5 + numDistortionParameters
+        α, β, γ, uc, vc = P[:5]
+        A = np.array([[α, γ, uc], [0, β, vc], [0, 0, 1]])
+        ext = P[start:].reshape(-1, 6)
+        W = mu.posesFromRT(mu.eulerToRotationMatrices(ext[:, :3]), ext[:, 3:])
+        return A, list(W), P[5:start]
+
+    def _printIterationStats(self, iter, ts, Pt, error, λ):
+        """src/calibrate.py:269-274 (A and k of the current parameters)"""
+        nk = len(self._distortionModel.getDistortionSymbols())
+        α, β, γ, uc, vc = Pt[:5]
+        At = np.array([[α, γ, uc], [0, β, vc], [0, 0, 1]])
+        print(f"\niter {iter}: ({time.time() - ts:0.3f}s), error={error:0.3f}, λ={λ:e}")
+        print(f"A:\n{At}")
+        print(f"k:\n{Pt[5:5 + nk]}")
+
+
+def getSensorPoints(allDetections):
+    """(MN,2) stack of every view's sensor points (src/calibrate.py:277-282)"""
+    if len(allDetections) == 0:
+        return np.empty((0, 2))
+    return np.vstack([np.asarray(s, dtype=np.float64).reshape(-1, 2) for s, m in allDetections])

@@ -1,0 +1,739 @@
+// C-ABI host side of the LM refinement engine (see include/calib_lm.h).
+// Owns device memory, packs correspondences to SoA, sequences the kernels of kernels.hpp.
+#include "../../include/calib_lm.h"
+#include "kernels.hpp"
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace calib;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            return fail(CALIB_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));     \
+    } while (0)
+
+#define CHECK_H(h)                                                                            \
+    if (!(h)) return fail(CALIB_E_INVALID, "null handle");                                    \
+    HIP_TRY(hipSetDevice((h)->device))
+
+template <typename U>
+struct DevBuf {
+    U* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        release();
+        if (count == 0) return hipSuccess;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(U));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+constexpr int kEventPool = 4096;
+
+}  // namespace
+
+struct calib_handle_s {
+    int model = 0, dtype = 0, device = 0;
+    int L = 10, C = 16;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+
+    // problem
+    bool has_problem = false;
+    int64_t M = 0, MN = 0;        // external views, points
+    int nv = 0;                   // non-empty views
+    int n_items = 0;
+    int64_t n_tiles = 0;
+    int max_views_per_tile = 1;
+    int schur_blocks = 1;
+    DevBuf<unsigned char> uv, XY, Z, VC, J, r, y;   // typed by dtype
+    DevBuf<int> pt_view, view_ext, item_n, view_item0;
+    DevBuf<int64_t> item_pt0;
+    DevBuf<double> sse_part, G[2], part, red_own, P[2], Peval, trace;
+    DevBuf<LMState> st, st_eval;
+    double* red = nullptr;        // active reduce buffer (own or bound)
+    bool lm_active = false;
+    int lm_max_iters = 0;
+    int rounds_enqueued = 0;
+
+    // profiling
+    bool prof = false;
+    std::vector<hipEvent_t> ev;   // pairs
+    std::vector<int> ev_kind;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+size_t tsize(const calib_handle_s* h) { return h->dtype == CALIB_DTYPE_F64 ? 8 : 4; }
+
+int prof_begin(calib_handle_s* h, int kind) {
+    if (!h->prof || h->ev_used + 2 > h->ev.size()) return -1;
+    int idx = (int)h->ev_used;
+    h->ev_used += 2;
+    h->ev_kind[idx / 2] = kind;
+    (void)hipEventRecord(h->ev[idx], h->stream);
+    return idx;
+}
+void prof_end(calib_handle_s* h, int idx) {
+    if (idx >= 0) (void)hipEventRecord(h->ev[idx + 1], h->stream);
+}
+
+// ---- launches ---------------------------------------------------------------------------
+template <typename T>
+int launch_view_setup(calib_handle_s* h, const double* P0, const double* P1, const LMState* st, int sel) {
+    if (h->nv == 0) return CALIB_OK;
+    const int threads = 64;
+    const int blocks = (h->nv + threads - 1) / threads;
+    hipLaunchKernelGGL((view_setup_kernel<T>), dim3(blocks), dim3(threads), 0, h->stream, P0, P1, st, sel,
+                       h->L, h->view_ext.p, h->nv, reinterpret_cast<T*>(h->VC.p));
+    HIP_TRY(hipGetLastError());
+    return CALIB_OK;
+}
+
+template <int MODEL, typename T>
+int launch_jacobian_t(calib_handle_s* h, const double* P0, const double* P1, const LMState* st, int sel,
+                      bool wantJ, bool wantR, bool wantY) {
+    using T2 = typename Pair<T>::type;
+    if (h->MN == 0) return CALIB_OK;
+    JacArgs<T> a;
+    a.P0 = P0; a.P1 = P1; a.st = st; a.sel = sel;
+    a.uv = reinterpret_cast<const T2*>(h->uv.p);
+    a.XY = reinterpret_cast<const T2*>(h->XY.p);
+    a.Z = reinterpret_cast<const T*>(h->Z.p);
+    a.pt_view = h->pt_view.p;
+    a.MN = h->MN;
+    a.VC = reinterpret_cast<const T*>(h->VC.p);
+    a.J = wantJ ? reinterpret_cast<T2*>(h->J.p) : nullptr;
+    a.r = wantR ? reinterpret_cast<T2*>(h->r.p) : nullptr;
+    a.y = wantY ? reinterpret_cast<T2*>(h->y.p) : nullptr;
+    a.sse_part = h->sse_part.p;
+    const size_t lds = 32 + (size_t)h->max_views_per_tile * kViewStride * sizeof(T);
+    int pi = prof_begin(h, 0);
+    hipLaunchKernelGGL((jacobian_kernel<MODEL, T>), dim3((unsigned)h->n_tiles), dim3(kTile), lds, h->stream, a);
+    prof_end(h, pi);
+    HIP_TRY(hipGetLastError());
+    return CALIB_OK;
+}
+
+int launch_jacobian(calib_handle_s* h, const double* P0, const double* P1, const LMState* st, int sel,
+                    bool wantJ, bool wantR, bool wantY) {
+    if (h->dtype == CALIB_DTYPE_F64) {
+        int rc = launch_view_setup<double>(h, P0, P1, st, sel);
+        if (rc) return rc;
+        return h->model == CALIB_MODEL_RADTAN
+                   ? launch_jacobian_t<kRadtan, double>(h, P0, P1, st, sel, wantJ, wantR, wantY)
+                   : launch_jacobian_t<kFisheye, double>(h, P0, P1, st, sel, wantJ, wantR, wantY);
+    }
+    int rc = launch_view_setup<float>(h, P0, P1, st, sel);
+    if (rc) return rc;
+    return h->model == CALIB_MODEL_RADTAN
+               ? launch_jacobian_t<kRadtan, float>(h, P0, P1, st, sel, wantJ, wantR, wantY)
+               : launch_jacobian_t<kFisheye, float>(h, P0, P1, st, sel, wantJ, wantR, wantY);
+}
+
+template <typename T, int C>
+int launch_gram_t(calib_handle_s* h, const LMState* st, int sel) {
+    using T2 = typename Pair<T>::type;
+    if (h->n_items == 0) return CALIB_OK;
+    const int blocks = (h->n_items + 3) / 4;
+    int pi = prof_begin(h, 1);
+    hipLaunchKernelGGL((gram_kernel<T, C>), dim3(blocks), dim3(256), 0, h->stream,
+                       reinterpret_cast<const T2*>(h->J.p), reinterpret_cast<const T2*>(h->r.p),
+                       h->item_pt0.p, h->item_n.p, h->n_items, st, sel, h->G[0].p, h->G[1].p);
+    prof_end(h, pi);
+    HIP_TRY(hipGetLastError());
+    return CALIB_OK;
+}
+
+int launch_gram(calib_handle_s* h, const LMState* st, int sel) {
+    if (h->dtype == CALIB_DTYPE_F64)
+        return h->model == CALIB_MODEL_RADTAN ? launch_gram_t<double, 16>(h, st, sel)
+                                              : launch_gram_t<double, 15>(h, st, sel);
+    return h->model == CALIB_MODEL_RADTAN ? launch_gram_t<float, 16>(h, st, sel)
+                                          : launch_gram_t<float, 15>(h, st, sel);
+}
+
+int launch_schur_reduce(calib_handle_s* h, const LMState* st, double* red) {
+    const int VA = variantSize(h->L);
+    if (h->nv > 0) {
+        dim3 grid(h->schur_blocks, 2);
+        if (h->L == 10)
+            hipLaunchKernelGGL((schur_kernel<10>), grid, dim3(kSchurThreads), 0, h->stream, h->G[0].p,
+                               h->G[1].p, st, h->view_item0.p, h->nv, h->part.p);
+        else
+            hipLaunchKernelGGL((schur_kernel<9>), grid, dim3(kSchurThreads), 0, h->stream, h->G[0].p,
+                               h->G[1].p, st, h->view_item0.p, h->nv, h->part.p);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->part.p,
+                       h->nv > 0 ? h->schur_blocks : 0, VA, h->sse_part.p, h->n_tiles, st, red);
+    HIP_TRY(hipGetLastError());
+    return CALIB_OK;
+}
+
+int launch_update_backsub(calib_handle_s* h) {
+    LMState* st = h->st.p;
+    if (h->L == 10)
+        hipLaunchKernelGGL((update_kernel<10>), dim3(1), dim3(64), 0, h->stream, st, h->red, h->P[0].p,
+                           h->P[1].p, h->trace.p);
+    else
+        hipLaunchKernelGGL((update_kernel<9>), dim3(1), dim3(64), 0, h->stream, st, h->red, h->P[0].p,
+                           h->P[1].p, h->trace.p);
+    HIP_TRY(hipGetLastError());
+    if (h->nv > 0) {
+        const int per = kSchurThreads / 16;
+        const int blocks = (h->nv + per - 1) / per;
+        if (h->L == 10)
+            hipLaunchKernelGGL((backsub_kernel<10>), dim3(blocks), dim3(kSchurThreads), 0, h->stream,
+                               h->G[0].p, h->G[1].p, st, h->view_item0.p, h->view_ext.p, h->nv,
+                               h->P[0].p, h->P[1].p);
+        else
+            hipLaunchKernelGGL((backsub_kernel<9>), dim3(blocks), dim3(kSchurThreads), 0, h->stream,
+                               h->G[0].p, h->G[1].p, st, h->view_item0.p, h->view_ext.p, h->nv,
+                               h->P[0].p, h->P[1].p);
+        HIP_TRY(hipGetLastError());
+    }
+    return CALIB_OK;
+}
+
+int need_problem(calib_handle_s* h) {
+    if (!h->has_problem) return fail(CALIB_E_STATE, "calib_set_problem has not been called");
+    return CALIB_OK;
+}
+
+int64_t numParams(const calib_handle_s* h) { return h->L + 6 * h->M; }
+
+}  // namespace
+
+// ============================================================================ C-ABI
+extern "C" {
+
+int calib_version(void) { return 100; }
+
+const char* calib_last_error(void) { return g_err.c_str(); }
+
+int calib_device_count(int* out_count) {
+    if (!out_count) return fail(CALIB_E_INVALID, "out_count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *out_count = 0;
+        return fail(CALIB_E_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *out_count = n;
+    return CALIB_OK;
+}
+
+int calib_create(int model, int dtype, int device_id, calib_handle_t* out_handle) {
+    if (!out_handle) return fail(CALIB_E_INVALID, "out_handle is null");
+    *out_handle = nullptr;
+    if (model != CALIB_MODEL_RADTAN && model != CALIB_MODEL_FISHEYE)
+        return fail(CALIB_E_INVALID, "unknown distortion model");
+    if (dtype != CALIB_DTYPE_F64 && dtype != CALIB_DTYPE_F32)
+        return fail(CALIB_E_INVALID, "unknown dtype");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n)
+        return fail(CALIB_E_HIP, "no such HIP device (this library has no CPU fallback)");
+    HIP_TRY(hipSetDevice(device_id));
+    calib_handle_s* h = new (std::nothrow) calib_handle_s();
+    if (!h) return fail(CALIB_E_INVALID, "out of host memory");
+    h->model = model;
+    h->dtype = dtype;
+    h->device = device_id;
+    h->L = model == CALIB_MODEL_RADTAN ? 10 : 9;
+    h->C = h->L + 6;
+    hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(CALIB_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    h->stream = h->own_stream;
+    *out_handle = h;
+    return CALIB_OK;
+}
+
+int calib_destroy(calib_handle_t h) {
+    if (!h) return CALIB_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& e : h->ev) (void)hipEventDestroy(e);
+    h->uv.release(); h->XY.release(); h->Z.release(); h->VC.release(); h->J.release();
+    h->r.release(); h->y.release(); h->pt_view.release(); h->view_ext.release();
+    h->item_n.release(); h->view_item0.release(); h->item_pt0.release(); h->sse_part.release();
+    h->G[0].release(); h->G[1].release(); h->part.release(); h->red_own.release();
+    h->P[0].release(); h->P[1].release(); h->Peval.release(); h->trace.release();
+    h->st.release(); h->st_eval.release();
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return CALIB_OK;
+}
+
+int calib_set_stream(calib_handle_t h, void* hip_stream) {
+    CHECK_H(h);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return CALIB_OK;
+}
+
+int calib_num_shared(calib_handle_t h, int* out_L) {
+    if (!h || !out_L) return fail(CALIB_E_INVALID, "null argument");
+    *out_L = h->L;
+    return CALIB_OK;
+}
+
+int calib_num_params(calib_handle_t h, int64_t* out_K) {
+    if (!h || !out_K) return fail(CALIB_E_INVALID, "null argument");
+    *out_K = numParams(h);
+    return CALIB_OK;
+}
+
+int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_offsets,
+                      const double* sensor_uv, const double* model_xyz) {
+    CHECK_H(h);
+    if (num_views < 0 || !view_offsets) return fail(CALIB_E_INVALID, "bad view_offsets");
+    if (view_offsets[0] != 0) return fail(CALIB_E_INVALID, "view_offsets[0] must be 0");
+    for (int64_t i = 0; i < num_views; ++i)
+        if (view_offsets[i + 1] < view_offsets[i])
+            return fail(CALIB_E_INVALID, "view_offsets must be non-decreasing");
+    const int64_t MN = view_offsets[num_views];
+    if (MN > 0 && !model_xyz) return fail(CALIB_E_INVALID, "model_xyz is null");
+    if (num_views > 0x7fffffffLL / 8 || MN > (int64_t)1 << 40)
+        return fail(CALIB_E_INVALID, "problem too large for one shard");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->has_problem = false;
+    h->lm_active = false;
+    h->M = num_views;
+    h->MN = MN;
+
+    // host-side packing: SoA + compact (non-empty) view list + gram work items
+    std::vector<int> pt_view((size_t)MN), view_ext, item_n, view_item0;
+    std::vector<int64_t> item_pt0;
+    view_item0.push_back(0);
+    for (int64_t i = 0; i < num_views; ++i) {
+        const int64_t a = view_offsets[i], b = view_offsets[i + 1];
+        if (b == a) continue;
+        const int cv = (int)view_ext.size();
+        view_ext.push_back((int)i);
+        for (int64_t p = a; p < b; ++p) pt_view[(size_t)p] = cv;
+        for (int64_t p = a; p < b; p += kGramChunk) {
+            item_pt0.push_back(p);
+            item_n.push_back((int)std::min<int64_t>(kGramChunk, b - p));
+        }
+        view_item0.push_back((int)item_pt0.size());
+    }
+    h->nv = (int)view_ext.size();
+    h->n_items = (int)item_pt0.size();
+    h->n_tiles = (MN + kTile - 1) / kTile;
+    int mv = 1;
+    for (int64_t t = 0; t < h->n_tiles; ++t) {
+        const int64_t a = t * kTile, b = std::min<int64_t>(MN, a + kTile) - 1;
+        mv = std::max(mv, pt_view[(size_t)b] - pt_view[(size_t)a] + 1);
+    }
+    h->max_views_per_tile = mv;
+    const int per = kSchurThreads / 16;
+    h->schur_blocks = std::max(1, std::min(kMaxSchurBlocks, (h->nv + per - 1) / per));
+
+    const size_t ts = tsize(h);
+    HIP_TRY(h->uv.alloc((size_t)MN * 2 * ts));
+    HIP_TRY(h->XY.alloc((size_t)MN * 2 * ts));
+    HIP_TRY(h->Z.alloc((size_t)MN * ts));
+    HIP_TRY(h->pt_view.alloc((size_t)MN));
+    HIP_TRY(h->view_ext.alloc((size_t)h->nv));
+    HIP_TRY(h->item_n.alloc((size_t)h->n_items));
+    HIP_TRY(h->item_pt0.alloc((size_t)h->n_items));
+    HIP_TRY(h->view_item0.alloc((size_t)h->nv + 1));
+    HIP_TRY(h->VC.alloc((size_t)std::max(h->nv, 1) * kViewStride * ts));
+    HIP_TRY(h->r.alloc((size_t)MN * 2 * ts));
+    HIP_TRY(h->sse_part.alloc((size_t)std::max<int64_t>(h->n_tiles, 1)));
+    HIP_TRY(h->st_eval.alloc(1));
+    HIP_TRY(hipMemsetAsync(h->st_eval.p, 0, sizeof(LMState), h->stream));
+    HIP_TRY(h->Peval.alloc((size_t)numParams(h)));
+
+    auto upload = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+        if (bytes == 0) return hipSuccess;
+        return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    if (h->dtype == CALIB_DTYPE_F64) {
+        std::vector<double> xy((size_t)MN * 2), z((size_t)MN);
+        for (int64_t p = 0; p < MN; ++p) {
+            xy[2 * p] = model_xyz[3 * p]; xy[2 * p + 1] = model_xyz[3 * p + 1]; z[p] = model_xyz[3 * p + 2];
+        }
+        HIP_TRY(upload(h->XY.p, xy.data(), xy.size() * 8));
+        HIP_TRY(upload(h->Z.p, z.data(), z.size() * 8));
+        if (sensor_uv) HIP_TRY(upload(h->uv.p, sensor_uv, (size_t)MN * 16));
+        else if (MN) HIP_TRY(hipMemset(h->uv.p, 0, (size_t)MN * 16));
+    } else {
+        std::vector<float> xy((size_t)MN * 2), z((size_t)MN), uv((size_t)MN * 2, 0.f);
+        for (int64_t p = 0; p < MN; ++p) {
+            xy[2 * p] = (float)model_xyz[3 * p]; xy[2 * p + 1] = (float)model_xyz[3 * p + 1];
+            z[p] = (float)model_xyz[3 * p + 2];
+            if (sensor_uv) { uv[2 * p] = (float)sensor_uv[2 * p]; uv[2 * p + 1] = (float)sensor_uv[2 * p + 1]; }
+        }
+        HIP_TRY(upload(h->XY.p, xy.data(), xy.size() * 4));
+        HIP_TRY(upload(h->Z.p, z.data(), z.size() * 4));
+        HIP_TRY(upload(h->uv.p, uv.data(), uv.size() * 4));
+    }
+    HIP_TRY(upload(h->pt_view.p, pt_view.data(), pt_view.size() * 4));
+    HIP_TRY(upload(h->view_ext.p, view_ext.data(), view_ext.size() * 4));
+    HIP_TRY(upload(h->item_n.p, item_n.data(), item_n.size() * 4));
+    HIP_TRY(upload(h->item_pt0.p, item_pt0.data(), item_pt0.size() * 8));
+    HIP_TRY(upload(h->view_item0.p, view_item0.data(), view_item0.size() * 4));
+    h->has_problem = true;
+    return CALIB_OK;
+}
+
+int calib_eval(calib_handle_t h, const double* P, double* out_y, double* out_r, double* out_Jc,
+               double* out_sse) {
+    CHECK_H(h);
+    int rc = need_problem(h);
+    if (rc) return rc;
+    if (!P) return fail(CALIB_E_INVALID, "P is null");
+    const size_t ts = tsize(h);
+    const int64_t MN = h->MN;
+    if (out_Jc) HIP_TRY(h->J.alloc((size_t)MN * h->C * 2 * ts));
+    if (out_y) HIP_TRY(h->y.alloc((size_t)MN * 2 * ts));
+    HIP_TRY(h->red_own.alloc((size_t)reduceSize(h->L)));
+    HIP_TRY(hipMemcpyAsync(h->Peval.p, P, (size_t)numParams(h) * 8, hipMemcpyHostToDevice, h->stream));
+    rc = launch_jacobian(h, h->Peval.p, nullptr, h->st_eval.p, 0, out_Jc != nullptr, out_r != nullptr,
+                         out_y != nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(256), 0, h->stream, (const double*)nullptr, 0, 0,
+                       h->sse_part.p, h->n_tiles, h->st_eval.p, h->red_own.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (out_sse) HIP_TRY(hipMemcpy(out_sse, h->red_own.p, 8, hipMemcpyDeviceToHost));
+
+    auto fetch2 = [&](const void* dev, double* out) -> int {   // (MN,2) of T -> double
+        if (h->dtype == CALIB_DTYPE_F64) {
+            HIP_TRY(hipMemcpy(out, dev, (size_t)MN * 16, hipMemcpyDeviceToHost));
+        } else {
+            std::vector<float> tmp((size_t)MN * 2);
+            HIP_TRY(hipMemcpy(tmp.data(), dev, tmp.size() * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < tmp.size(); ++i) out[i] = tmp[i];
+        }
+        return CALIB_OK;
+    };
+    if (out_y && MN) { rc = fetch2(h->y.p, out_y); if (rc) return rc; }
+    if (out_r && MN) { rc = fetch2(h->r.p, out_r); if (rc) return rc; }
+    if (out_Jc && MN) {
+        // device layout [MN][C](du,dv) -> caller layout (MN,2,C)
+        const int C = h->C;
+        const size_t cnt = (size_t)MN * C * 2;
+        std::vector<double> tmp(cnt);
+        if (h->dtype == CALIB_DTYPE_F64) {
+            HIP_TRY(hipMemcpy(tmp.data(), h->J.p, cnt * 8, hipMemcpyDeviceToHost));
+        } else {
+            std::vector<float> tf(cnt);
+            HIP_TRY(hipMemcpy(tf.data(), h->J.p, cnt * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < cnt; ++i) tmp[i] = tf[i];
+        }
+        for (int64_t p = 0; p < MN; ++p)
+            for (int c = 0; c < C; ++c) {
+                out_Jc[(p * 2 + 0) * C + c] = tmp[((size_t)p * C + c) * 2 + 0];
+                out_Jc[(p * 2 + 1) * C + c] = tmp[((size_t)p * C + c) * 2 + 1];
+            }
+    }
+    return CALIB_OK;
+}
+
+int calib_lm_reduce_size(calib_handle_t h, int64_t* out_num_doubles) {
+    if (!h || !out_num_doubles) return fail(CALIB_E_INVALID, "null argument");
+    *out_num_doubles = reduceSize(h->L);
+    return CALIB_OK;
+}
+
+int calib_lm_bind_reduce_buffer(calib_handle_t h, void* reduce_dev) {
+    CHECK_H(h);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(h->red_own.alloc((size_t)reduceSize(h->L)));
+    h->red = reduce_dev ? reinterpret_cast<double*>(reduce_dev) : h->red_own.p;
+    return CALIB_OK;
+}
+
+int calib_lm_begin(calib_handle_t h, const double* P0, int max_iters, double lam_init, double lam_min,
+                   double lam_max, double err_min) {
+    CHECK_H(h);
+    int rc = need_problem(h);
+    if (rc) return rc;
+    if (!P0) return fail(CALIB_E_INVALID, "P0 is null");
+    if (max_iters <= 0)
+        return fail(CALIB_E_INVALID, "max_iters must be >= 1 (the reference raises UnboundLocalError "
+                                     "for maxIters=0, src/calibrate.py:171)");
+    if (h->nv != h->M)
+        return fail(CALIB_E_SINGULAR, "a view without points makes J^T J + lambda diag(J^T J) singular");
+    const size_t ts = tsize(h);
+    const int64_t K = numParams(h);
+    HIP_TRY(h->J.alloc((size_t)h->MN * h->C * 2 * ts));
+    HIP_TRY(h->G[0].alloc((size_t)std::max(h->n_items, 1) * kGStride));
+    HIP_TRY(h->G[1].alloc((size_t)std::max(h->n_items, 1) * kGStride));
+    HIP_TRY(h->part.alloc((size_t)2 * h->schur_blocks * variantSize(h->L)));
+    HIP_TRY(h->red_own.alloc((size_t)reduceSize(h->L)));
+    if (!h->red) h->red = h->red_own.p;
+    HIP_TRY(h->P[0].alloc((size_t)K));
+    HIP_TRY(h->P[1].alloc((size_t)K));
+    HIP_TRY(h->st.alloc(1));
+    HIP_TRY(h->trace.alloc((size_t)max_iters * (CALIB_TRACE_HEADER + h->L)));
+    HIP_TRY(hipMemsetAsync(h->trace.p, 0, (size_t)max_iters * (CALIB_TRACE_HEADER + h->L) * 8, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->P[0].p, P0, (size_t)K * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->P[1].p, P0, (size_t)K * 8, hipMemcpyHostToDevice, h->stream));
+    LMState s;
+    std::memset(&s, 0, sizeof(s));
+    s.lam = lam_init; s.lam_min = lam_min; s.lam_max = lam_max; s.err_min = err_min;
+    s.cur = 1;            // round 0 evaluates the "candidate" buffer 0 == P0
+    s.max_iters = max_iters;
+    HIP_TRY(hipMemcpyAsync(h->st.p, &s, sizeof(s), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));     // s and P0 are host stack / caller memory
+    h->lm_active = true;
+    h->lm_max_iters = max_iters;
+    h->rounds_enqueued = 0;
+    return CALIB_OK;
+}
+
+int calib_lm_local(calib_handle_t h) {
+    CHECK_H(h);
+    if (!h->lm_active) return fail(CALIB_E_STATE, "calib_lm_begin has not been called");
+    int rc = launch_jacobian(h, h->P[0].p, h->P[1].p, h->st.p, 1, true, true, false);
+    if (rc) return rc;
+    rc = launch_gram(h, h->st.p, 1);
+    if (rc) return rc;
+    return launch_schur_reduce(h, h->st.p, h->red);
+}
+
+int calib_lm_update(calib_handle_t h) {
+    CHECK_H(h);
+    if (!h->lm_active) return fail(CALIB_E_STATE, "calib_lm_begin has not been called");
+    h->rounds_enqueued += 1;
+    return launch_update_backsub(h);
+}
+
+int calib_lm_done(calib_handle_t h, int* out_done) {
+    CHECK_H(h);
+    if (!h->lm_active || !out_done) return fail(CALIB_E_STATE, "no LM run active");
+    LMState s;
+    HIP_TRY(hipMemcpyAsync(&s, h->st.p, sizeof(s), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *out_done = s.done;
+    return CALIB_OK;
+}
+
+int calib_lm_peek_trace(calib_handle_t h, int iter, double* out_row, int* out_iters) {
+    CHECK_H(h);
+    if (!h->lm_active || !out_row || !out_iters) return fail(CALIB_E_STATE, "no LM run active");
+    if (iter < 0 || iter >= h->lm_max_iters) return fail(CALIB_E_INVALID, "trace row out of range");
+    LMState s;
+    const size_t w = (size_t)(CALIB_TRACE_HEADER + h->L);
+    HIP_TRY(hipMemcpyAsync(&s, h->st.p, sizeof(s), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(out_row, h->trace.p + (size_t)iter * w, w * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *out_iters = s.iters;
+    return CALIB_OK;
+}
+
+int calib_lm_run(calib_handle_t h, int rounds, int check_every) {
+    CHECK_H(h);
+    if (!h->lm_active) return fail(CALIB_E_STATE, "calib_lm_begin has not been called");
+    for (int i = 0; i < rounds; ++i) {
+        int rc = calib_lm_local(h);
+        if (rc) return rc;
+        rc = calib_lm_update(h);
+        if (rc) return rc;
+        if (check_every > 0 && (i + 1) % check_every == 0 && i + 1 < rounds) {
+            int done = 0;
+            rc = calib_lm_done(h, &done);
+            if (rc) return rc;
+            if (done) break;
+        }
+    }
+    return CALIB_OK;
+}
+
+int calib_lm_end(calib_handle_t h, double* P_out, double* out_sse, int* out_iters, double* out_trace) {
+    CHECK_H(h);
+    if (!h->lm_active) return fail(CALIB_E_STATE, "no LM run active");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    LMState s;
+    HIP_TRY(hipMemcpy(&s, h->st.p, sizeof(s), hipMemcpyDeviceToHost));
+    h->lm_active = false;
+    if (s.error == CALIB_E_SINGULAR)
+        return fail(CALIB_E_SINGULAR, "Singular matrix: damped normal equations are not invertible");
+    // after the bootstrap round cur points at the current parameters
+    const int cur = s.round == 0 ? 0 : s.cur;
+    if (P_out) HIP_TRY(hipMemcpy(P_out, h->P[cur].p, (size_t)numParams(h) * 8, hipMemcpyDeviceToHost));
+    if (out_sse) *out_sse = s.last_err;
+    if (out_iters) *out_iters = s.iters;
+    if (out_trace && s.iters > 0)
+        HIP_TRY(hipMemcpy(out_trace, h->trace.p, (size_t)s.iters * (CALIB_TRACE_HEADER + h->L) * 8,
+                          hipMemcpyDeviceToHost));
+    return CALIB_OK;
+}
+
+int calib_refine(calib_handle_t h, double* P_inout, int max_iters, double lam_init, double lam_min,
+                 double lam_max, double err_min, double* out_sse, int* out_iters, double* out_trace) {
+    int rc = calib_lm_begin(h, P_inout, max_iters, lam_init, lam_min, lam_max, err_min);
+    if (rc) return rc;
+    rc = calib_lm_run(h, max_iters + 1, 8);
+    if (rc) return rc;
+    return calib_lm_end(h, P_inout, out_sse, out_iters, out_trace);
+}
+
+int calib_lm_step_delta(calib_handle_t h, const double* P, double lambda, double* out_delta) {
+    if (!out_delta) return fail(CALIB_E_INVALID, "out_delta is null");
+    int rc = calib_lm_begin(h, P, 1, lambda, 0.0, INFINITY, -INFINITY);
+    if (rc) return rc;
+    rc = calib_lm_run(h, 1, 0);     // bootstrap round: evaluates P, solves, writes P + delta
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    LMState s;
+    HIP_TRY(hipMemcpy(&s, h->st.p, sizeof(s), hipMemcpyDeviceToHost));
+    h->lm_active = false;
+    if (s.error == CALIB_E_SINGULAR)
+        return fail(CALIB_E_SINGULAR, "Singular matrix: damped normal equations are not invertible");
+    const int64_t K = numParams(h);
+    std::vector<double> cand((size_t)K);
+    HIP_TRY(hipMemcpy(cand.data(), h->P[s.cur ^ 1].p, (size_t)K * 8, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < K; ++i) out_delta[i] = cand[(size_t)i] - P[i];
+    return CALIB_OK;
+}
+
+int calib_normal_eq(calib_handle_t h, const double* P, double* out_B, double* out_E, double* out_V,
+                    double* out_g) {
+    // bootstrap round with lambda = 0: variant A of the reduce buffer carries sum B and g_c,
+    // the per-view Gram blocks carry E_i, V_i, g_i.
+    int rc = calib_lm_begin(h, P, 1, 0.0, 0.0, INFINITY, -INFINITY);
+    if (rc) return rc;
+    rc = calib_lm_local(h);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->lm_active = false;
+    const int L = h->L;
+    std::vector<double> red((size_t)reduceSize(L));
+    HIP_TRY(hipMemcpy(red.data(), h->red, red.size() * 8, hipMemcpyDeviceToHost));
+    if (out_B) std::memcpy(out_B, red.data() + 1, (size_t)L * L * 8);
+    if (out_g) std::memcpy(out_g, red.data() + 1 + 2 * L * L, (size_t)L * 8);
+    if (out_E || out_V || out_g) {
+        std::vector<double> G((size_t)h->n_items * kGStride);
+        std::vector<int> vi0((size_t)h->nv + 1);
+        HIP_TRY(hipMemcpy(G.data(), h->G[0].p, G.size() * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(vi0.data(), h->view_item0.p, vi0.size() * 4, hipMemcpyDeviceToHost));
+        for (int v = 0; v < h->nv; ++v) {       // nv == M here (calib_lm_begin checked)
+            double blk[kGStride];
+            std::fill(blk, blk + kGStride, 0.0);
+            for (int it = vi0[v]; it < vi0[v + 1]; ++it)
+                for (int i = 0; i < kGStride; ++i) blk[i] += G[(size_t)it * kGStride + i];
+            for (int a = 0; a < 6; ++a) {
+                if (out_g) out_g[L + 6 * (int64_t)v + a] = blk[256 + L + a];
+                for (int b = 0; b < 6; ++b)
+                    if (out_V) out_V[((int64_t)v * 6 + a) * 6 + b] = blk[(L + a) * 16 + L + b];
+                for (int c = 0; c < L; ++c)
+                    if (out_E) out_E[((int64_t)v * L + c) * 6 + a] = blk[c * 16 + L + a];
+            }
+        }
+    }
+    return CALIB_OK;
+}
+
+int calib_distort_points(int model, int64_t n, const double* x_norm, const double* k, double* out_xd) {
+    if (n < 0 || (n > 0 && (!x_norm || !out_xd)) || !k) return fail(CALIB_E_INVALID, "null argument");
+    if (model != CALIB_MODEL_RADTAN && model != CALIB_MODEL_FISHEYE)
+        return fail(CALIB_E_INVALID, "unknown distortion model");
+    if (n == 0) return CALIB_OK;
+    const int nk = model == CALIB_MODEL_RADTAN ? 5 : 4;
+    DevBuf<double> dx, dk, dout;
+    HIP_TRY(dx.alloc((size_t)n * 2)); HIP_TRY(dk.alloc(nk)); HIP_TRY(dout.alloc((size_t)n * 2));
+    HIP_TRY(hipMemcpy(dx.p, x_norm, (size_t)n * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dk.p, k, (size_t)nk * 8, hipMemcpyHostToDevice));
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (model == CALIB_MODEL_RADTAN)
+        hipLaunchKernelGGL((distort_points_kernel<kRadtan>), dim3(blocks), dim3(256), 0, 0, dx.p, dk.p, n, dout.p);
+    else
+        hipLaunchKernelGGL((distort_points_kernel<kFisheye>), dim3(blocks), dim3(256), 0, 0, dx.p, dk.p, n, dout.p);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out_xd, dout.p, (size_t)n * 16, hipMemcpyDeviceToHost);
+    dx.release(); dk.release(); dout.release();
+    if (e != hipSuccess) return fail(CALIB_E_HIP, hipGetErrorString(e));
+    return CALIB_OK;
+}
+
+int calib_project_with_distortion(int model, int64_t n, const double* A, const double* cam_xyz,
+                                  const double* k, double* out_uv) {
+    if (n < 0 || (n > 0 && (!cam_xyz || !out_uv)) || !k || !A) return fail(CALIB_E_INVALID, "null argument");
+    if (model != CALIB_MODEL_RADTAN && model != CALIB_MODEL_FISHEYE)
+        return fail(CALIB_E_INVALID, "unknown distortion model");
+    if (n == 0) return CALIB_OK;
+    const int nk = model == CALIB_MODEL_RADTAN ? 5 : 4;
+    DevBuf<double> dA, dc, dk, dout;
+    HIP_TRY(dA.alloc(9)); HIP_TRY(dc.alloc((size_t)n * 3)); HIP_TRY(dk.alloc(nk)); HIP_TRY(dout.alloc((size_t)n * 2));
+    HIP_TRY(hipMemcpy(dA.p, A, 72, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dc.p, cam_xyz, (size_t)n * 24, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dk.p, k, (size_t)nk * 8, hipMemcpyHostToDevice));
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (model == CALIB_MODEL_RADTAN)
+        hipLaunchKernelGGL((project_cam_kernel<kRadtan>), dim3(blocks), dim3(256), 0, 0, dA.p, dc.p, dk.p, n, dout.p);
+    else
+        hipLaunchKernelGGL((project_cam_kernel<kFisheye>), dim3(blocks), dim3(256), 0, 0, dA.p, dc.p, dk.p, n, dout.p);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out_uv, dout.p, (size_t)n * 16, hipMemcpyDeviceToHost);
+    dA.release(); dc.release(); dk.release(); dout.release();
+    if (e != hipSuccess) return fail(CALIB_E_HIP, hipGetErrorString(e));
+    return CALIB_OK;
+}
+
+int calib_profile_enable(calib_handle_t h, int on) {
+    CHECK_H(h);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (on && h->ev.empty()) {
+        h->ev.resize(kEventPool);
+        h->ev_kind.assign(kEventPool / 2, 0);
+        for (auto& e : h->ev) HIP_TRY(hipEventCreate(&e));
+    }
+    h->prof = on != 0;
+    h->ev_used = 0;
+    return CALIB_OK;
+}
+
+int calib_profile_read(calib_handle_t h, int which, double* out_total_ms, int64_t* out_launches) {
+    CHECK_H(h);
+    if (!out_total_ms || !out_launches) return fail(CALIB_E_INVALID, "null argument");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    double total = 0.0;
+    int64_t count = 0;
+    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+        if (h->ev_kind[i / 2] != which) continue;
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+        total += ms;
+        count += 1;
+    }
+    *out_total_ms = total;
+    *out_launches = count;
+    return CALIB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+// Per-point projection + analytic Jacobian (device code, gfx950).
+//
+// Replaces the sympy-differentiated, lambdified expression the reference evaluates
+// per view (src/jacobian.py:19-36,147-172) by the closed-form chain rule through
+//   Pc = R(rho) Pw + t            src/distortion.py:26-37, src/mathutils.py:36-51
+//   (x, y) = Pc.xy / Pc.z          src/mathutils.py:174-192
+//   distort                        src/distortion.py:78-108 (radtan), :198-220 (fisheye)
+//   u = a xd + g yd + uc, v = b yd + vc    src/distortion.py:57-58
+// T is the storage/evaluation type (double or float).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace calib {
+
+constexpr int kRadtan = 0;
+constexpr int kFisheye = 1;
+
+template <int MODEL> struct ModelTraits;
+template <> struct ModelTraits<kRadtan>  { static constexpr int NK = 5; static constexpr int L = 10; static constexpr int C = 16; };
+template <> struct ModelTraits<kFisheye> { static constexpr int NK = 4; static constexpr int L = 9;  static constexpr int C = 15; };
+
+// Per-view constants staged through LDS (written by view_setup_kernel):
+//   [0..9)  R row-major   [9..12) t   [12..15) (pi/180) * Rz Ry e_x   [15..17) (pi/180) * (Rz e_y).xy
+constexpr int kViewStride = 18;
+
+template <typename T> struct Pair;
+template <> struct Pair<double> { using type = double2; };
+template <> struct Pair<float>  { using type = float2; };
+
+template <typename T> __device__ __forceinline__ T t_sqrt(T x);
+template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return sqrt(x); }
+template <> __device__ __forceinline__ float  t_sqrt<float>(float x)   { return sqrtf(x); }
+template <typename T> __device__ __forceinline__ T t_atan(T x);
+template <> __device__ __forceinline__ double t_atan<double>(double x) { return atan(x); }
+template <> __device__ __forceinline__ float  t_atan<float>(float x)   { return atanf(x); }
+
+template <int MODEL, typename T>
+struct Shared {               // the L shared parameters, converted once per thread
+    T al, be, ga, uc, vc;
+    T k[ModelTraits<MODEL>::NK];
+    __device__ __forceinline__ void load(const double* __restrict__ P) {
+        al = (T)P[0]; be = (T)P[1]; ga = (T)P[2]; uc = (T)P[3]; vc = (T)P[4];
+#pragma unroll
+        for (int j = 0; j < ModelTraits<MODEL>::NK; ++j) k[j] = (T)P[5 + j];
+    }
+};
+
+// Distortion value + first derivatives at normalised (x, y).
+// dk[j] = (dxd/dk_j, dyd/dk_j).
+template <int MODEL, typename T>
+__device__ __forceinline__ void distort(const T* __restrict__ k, T x, T y,
+                                        T& xd, T& yd, T& xd_x, T& xd_y, T& yd_y,
+                                        T (&dkx)[ModelTraits<MODEL>::NK],
+                                        T (&dky)[ModelTraits<MODEL>::NK]) {
+    const T r2 = x * x + y * y;
+    if constexpr (MODEL == kRadtan) {
+        const T k1 = k[0], k2 = k[1], p1 = k[2], p2 = k[3], k3 = k[4];
+        const T r4 = r2 * r2, r6 = r4 * r2;
+        const T rad = T(1) + r2 * (k1 + r2 * (k2 + r2 * k3));
+        const T drad = k1 + r2 * (T(2) * k2 + T(3) * k3 * r2);
+        const T xy = x * y, xx = x * x, yy = y * y;
+        xd = rad * x + T(2) * p1 * xy + p2 * (r2 + T(2) * xx);
+        yd = rad * y + p1 * (r2 + T(2) * yy) + T(2) * p2 * xy;
+        xd_x = rad + T(2) * xx * drad + T(2) * p1 * y + T(6) * p2 * x;
+        xd_y = T(2) * xy * drad + T(2) * p1 * x + T(2) * p2 * y;
+        yd_y = rad + T(2) * yy * drad + T(6) * p1 * y + T(2) * p2 * x;
+        dkx[0] = x * r2;  dky[0] = y * r2;
+        dkx[1] = x * r4;  dky[1] = y * r4;
+        dkx[2] = T(2) * xy;           dky[2] = r2 + T(2) * yy;
+        dkx[3] = r2 + T(2) * xx;      dky[3] = T(2) * xy;
+        dkx[4] = x * r6;  dky[4] = y * r6;
+    } else {
+        const T k1 = k[0], k2 = k[1], k3 = k[2], k4 = k[3];
+        const T r = t_sqrt<T>(r2);
+        const T th = t_atan<T>(r);
+        const T t2 = th * th;
+        const T poly = T(1) + t2 * (k1 + t2 * (k2 + t2 * (k3 + t2 * k4)));
+        const T gp = (T(1) + t2 * (T(3) * k1 + t2 * (T(5) * k2 + t2 * (T(7) * k3 + T(9) * k4 * t2))))
+                     / (T(1) + r2);
+        // s = theta poly / r, s_r / r = (g' - s) / r^2; analytic limits at r -> 0
+        // (the reference evaluates 0/0 = NaN exactly at r = 0, src/distortion.py:215).
+        T s, sror, thr;
+        if (r < T(1e-8)) {
+            s = T(1); thr = T(1); sror = T(2) * k1 - T(2) / T(3);
+        } else {
+            const T ir = T(1) / r;
+            thr = th * ir;
+            s = thr * poly;
+            sror = (gp - s) * ir * ir;
+        }
+        xd = s * x;  yd = s * y;
+        xd_x = s + x * x * sror;
+        xd_y = x * y * sror;
+        yd_y = s + y * y * sror;
+        T p = thr * t2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dkx[j] = x * p; dky[j] = y * p; p *= t2; }
+    }
+}
+
+// Forward projection only (candidate-error style evaluation).
+template <int MODEL, typename T>
+__device__ __forceinline__ void project_point(const Shared<MODEL, T>& sp, const T* __restrict__ vc,
+                                              T X, T Y, T Z, T& u, T& v) {
+    const T Xc = vc[0] * X + vc[1] * Y + vc[2] * Z + vc[9];
+    const T Yc = vc[3] * X + vc[4] * Y + vc[5] * Z + vc[10];
+    const T Zc = vc[6] * X + vc[7] * Y + vc[8] * Z + vc[11];
+    const T iz = T(1) / Zc;
+    T xd, yd, a, b, c;
+    T dkx[ModelTraits<MODEL>::NK], dky[ModelTraits<MODEL>::NK];
+    distort<MODEL, T>(sp.k, Xc * iz, Yc * iz, xd, yd, a, b, c, dkx, dky);
+    u = sp.al * xd + sp.ga * yd + sp.uc;
+    v = sp.be * yd + sp.vc;
+}
+
+// Projection + the point's 2 x C Jacobian block. Ju/Jv column order is the
+// reference's (src/jacobian.py:22-26): [alpha beta gamma uc vc | k.. | rx ry rz tx ty tz].
+template <int MODEL, typename T>
+__device__ __forceinline__ void jacobian_point(const Shared<MODEL, T>& sp, const T* __restrict__ vc,
+                                               T X, T Y, T Z, T& u, T& v,
+                                               T (&Ju)[ModelTraits<MODEL>::C],
+                                               T (&Jv)[ModelTraits<MODEL>::C]) {
+    constexpr int NK = ModelTraits<MODEL>::NK;
+    constexpr int L = ModelTraits<MODEL>::L;
+    const T q0 = vc[0] * X + vc[1] * Y + vc[2] * Z;
+    const T q1 = vc[3] * X + vc[4] * Y + vc[5] * Z;
+    const T q2 = vc[6] * X + vc[7] * Y + vc[8] * Z;
+    const T Xc = q0 + vc[9], Yc = q1 + vc[10], Zc = q2 + vc[11];
+    const T iz = T(1) / Zc;
+    const T x = Xc * iz, y = Yc * iz;
+
+    T xd, yd, xd_x, xd_y, yd_y;
+    T dkx[NK], dky[NK];
+    distort<MODEL, T>(sp.k, x, y, xd, yd, xd_x, xd_y, yd_y, dkx, dky);
+    const T yd_x = xd_y;
+
+    u = sp.al * xd + sp.ga * yd + sp.uc;
+    v = sp.be * yd + sp.vc;
+
+    Ju[0] = xd;   Jv[0] = T(0);
+    Ju[1] = T(0); Jv[1] = yd;
+    Ju[2] = yd;   Jv[2] = T(0);
+    Ju[3] = T(1); Jv[3] = T(0);
+    Ju[4] = T(0); Jv[4] = T(1);
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        Ju[5 + j] = sp.al * dkx[j] + sp.ga * dky[j];
+        Jv[5 + j] = sp.be * dky[j];
+    }
+    // d(u,v)/d(x,y), pre-scaled by 1/Zc
+    const T ux = (sp.al * xd_x + sp.ga * yd_x) * iz;
+    const T uy = (sp.al * xd_y + sp.ga * yd_y) * iz;
+    const T vx = sp.be * yd_x * iz;
+    const T vy = sp.be * yd_y * iz;
+    // dPc/drho. = (pi/180) a. x q,  a_x = Rz Ry e_x, a_y = Rz e_y, a_z = e_z  (q = R Pw)
+    const T ax0 = vc[12], ax1 = vc[13], ax2 = vc[14], ay0 = vc[15], ay1 = vc[16];
+    const T deg = T(0.017453292519943295);
+    T dX, dY, dZ, dx, dy;
+    // rho_x
+    dX = ax1 * q2 - ax2 * q1;  dY = ax2 * q0 - ax0 * q2;  dZ = ax0 * q1 - ax1 * q0;
+    dx = dX - x * dZ;  dy = dY - y * dZ;
+    Ju[L + 0] = ux * dx + uy * dy;  Jv[L + 0] = vx * dx + vy * dy;
+    // rho_y  (a_y.z = 0)
+    dX = ay1 * q2;  dY = -ay0 * q2;  dZ = ay0 * q1 - ay1 * q0;
+    dx = dX - x * dZ;  dy = dY - y * dZ;
+    Ju[L + 1] = ux * dx + uy * dy;  Jv[L + 1] = vx * dx + vy * dy;
+    // rho_z  (e_z x q = (-q1, q0, 0))
+    dx = -deg * q1;  dy = deg * q0;
+    Ju[L + 2] = ux * dx + uy * dy;  Jv[L + 2] = vx * dx + vy * dy;
+    // t
+    Ju[L + 3] = ux;  Jv[L + 3] = vx;
+    Ju[L + 4] = uy;  Jv[L + 4] = vy;
+    Ju[L + 5] = -(ux * x + uy * y);  Jv[L + 5] = -(vx * x + vy * y);
+}
+
+}  // namespace calib

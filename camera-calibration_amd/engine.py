@@ -1,0 +1,238 @@
+"""RefineEngine: one GPU shard of the LM refinement engine (thin wrapper over the C-ABI).
+
+Holds the correspondences of a set of views resident in HBM and evaluates
+projection / residual / Jacobian / normal equations / the whole LM loop there.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _native as nat
+
+LAMBDA_INITIAL = 1e-3      # Calibrator._λinitial      src/calibrate.py:13
+LAMBDA_MIN = 1e-10         # Calibrator._λmin          src/calibrate.py:14
+LAMBDA_MAX = 1e+10         # Calibrator._λmax          src/calibrate.py:15
+PT_ERROR_MIN = 1e-12       # Calibrator._Pt_error_min  src/calibrate.py:16
+
+MODEL_IDS = {"radtan": nat.MODEL_RADTAN, "fisheye": nat.MODEL_FISHEYE}
+NUM_SHARED = {nat.MODEL_RADTAN: 10, nat.MODEL_FISHEYE: 9}
+DTYPE_IDS = {"f64": nat.DTYPE_F64, "fp64": nat.DTYPE_F64, "float64": nat.DTYPE_F64,
+             "f32": nat.DTYPE_F32, "fp32": nat.DTYPE_F32, "float32": nat.DTYPE_F32}
+
+
+def packDetections(allDetections):
+    """list of (sensorPoints (N_i,2), modelPoints (N_i,3)) -> CSR offsets + stacked arrays.
+    The stacking is getSensorPoints' vstack (src/calibrate.py:277-282) done once."""
+    M = len(allDetections)
+    offs = np.zeros(M + 1, dtype=np.int64)
+    for i, (s, m) in enumerate(allDetections):
+        s = np.asarray(s)
+        m = np.asarray(m)
+        if s.ndim != 2 or s.shape[1] != 2 or m.ndim != 2 or m.shape[1] != 3 or s.shape[0] != m.shape[0]:
+            raise ValueError(f"view {i}: expected sensor (N,2) and model (N,3), got {s.shape} and {m.shape}")
+        offs[i + 1] = offs[i] + s.shape[0]
+    if M:
+        sensor = np.ascontiguousarray(np.vstack([np.asarray(s, dtype=np.float64).reshape(-1, 2)
+                                                 for s, m in allDetections]))
+        model = np.ascontiguousarray(np.vstack([np.asarray(m, dtype=np.float64).reshape(-1, 3)
+                                                for s, m in allDetections]))
+    else:
+        sensor, model = np.empty((0, 2)), np.empty((0, 3))
+    return offs, sensor, model
+
+
+def packModelPoints(allModelPoints):
+    M = len(allModelPoints)
+    offs = np.zeros(M + 1, dtype=np.int64)
+    for i, m in enumerate(allModelPoints):
+        m = np.asarray(m)
+        if m.ndim != 2 or m.shape[1] != 3:
+            raise ValueError(f"view {i}: expected model points (N,3), got {m.shape}")
+        offs[i + 1] = offs[i] + m.shape[0]
+    model = (np.ascontiguousarray(np.vstack([np.asarray(m, dtype=np.float64).reshape(-1, 3)
+                                             for m in allModelPoints]))
+             if M else np.empty((0, 3)))
+    return offs, model
+
+
+class RefineEngine:
+    def __init__(self, model, dtype="f64", device=0):
+        self._lib = nat.loadLibrary()
+        nat.requireDevice()
+        self.modelId = MODEL_IDS[model] if isinstance(model, str) else int(model)
+        self.dtypeId = DTYPE_IDS[dtype] if isinstance(dtype, str) else int(dtype)
+        self.L = NUM_SHARED[self.modelId]
+        self.C = self.L + 6
+        h = ctypes.c_void_p()
+        nat.check(self._lib.calib_create(self.modelId, self.dtypeId, int(device), ctypes.byref(h)))
+        self._h = h
+        self.M = 0
+        self.MN = 0
+        self._lmMaxIters = 0
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.calib_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def K(self):
+        return self.L + 6 * self.M
+
+    # ---- problem -------------------------------------------------------------------------
+    def setProblem(self, viewOffsets, sensorPoints, modelPoints):
+        offs = np.ascontiguousarray(viewOffsets, dtype=np.int64)
+        if offs.ndim != 1 or offs.shape[0] < 1:
+            raise ValueError("viewOffsets must be a 1-D array of length M+1")
+        MN = int(offs[-1])
+        model = np.ascontiguousarray(modelPoints, dtype=np.float64).reshape(-1, 3)
+        if model.shape[0] != MN:
+            raise ValueError(f"Expected shape ({MN}, 3), got {model.shape}")
+        sensor = None
+        if sensorPoints is not None:
+            sensor = np.ascontiguousarray(sensorPoints, dtype=np.float64).reshape(-1, 2)
+            if sensor.shape[0] != MN:
+                raise ValueError(f"Expected shape ({MN}, 2), got {sensor.shape}")
+        nat.check(self._lib.calib_set_problem(self._h, offs.shape[0] - 1, nat.i64ptr(offs),
+                                              nat.dptr(sensor), nat.dptr(model)))
+        self.M = offs.shape[0] - 1
+        self.MN = MN
+        self.viewOffsets = offs
+
+    def setStream(self, hipStream):
+        nat.check(self._lib.calib_set_stream(self._h, ctypes.c_void_p(hipStream or 0)))
+
+    def _P(self, P):
+        P = np.ascontiguousarray(np.asarray(P, dtype=np.float64).ravel())
+        if P.shape[0] != self.K:
+            raise ValueError(f"Expected shape ({self.K},), got {P.shape}")
+        return P
+
+    # ---- single evaluations --------------------------------------------------------------
+    def evaluate(self, P, wantY=False, wantR=False, wantJ=False):
+        """-> dict with any of y (MN,2), r (MN,2), Jc (MN,2,C) and sse."""
+        P = self._P(P)
+        y = np.empty((self.MN, 2)) if wantY else None
+        r = np.empty((self.MN, 2)) if wantR else None
+        Jc = np.empty((self.MN, 2, self.C)) if wantJ else None
+        sse = ctypes.c_double(0.0)
+        nat.check(self._lib.calib_eval(self._h, nat.dptr(P), nat.dptr(y), nat.dptr(r), nat.dptr(Jc),
+                                       ctypes.byref(sse)))
+        return {"y": y, "r": r, "Jc": Jc, "sse": sse.value}
+
+    def normalEquations(self, P):
+        """-> B (L,L), E (M,L,6), V (M,6,6), g (K,): the block-arrow J^T J and J^T r."""
+        P = self._P(P)
+        B = np.empty((self.L, self.L))
+        E = np.empty((self.M, self.L, 6))
+        V = np.empty((self.M, 6, 6))
+        g = np.empty(self.K)
+        nat.check(self._lib.calib_normal_eq(self._h, nat.dptr(P), nat.dptr(B), nat.dptr(E), nat.dptr(V),
+                                            nat.dptr(g)))
+        return B, E, V, g
+
+    def stepDelta(self, P, lam):
+        P = self._P(P)
+        d = np.empty(self.K)
+        nat.check(self._lib.calib_lm_step_delta(self._h, nat.dptr(P), float(lam), nat.dptr(d)))
+        return d
+
+    # ---- LM ------------------------------------------------------------------------------
+    def refine(self, P0, maxIters, lamInit=LAMBDA_INITIAL, lamMin=LAMBDA_MIN, lamMax=LAMBDA_MAX,
+               errMin=PT_ERROR_MIN):
+        """Whole loop of src/calibrate.py:143-171 on the device.
+        -> (sse [pre-update, as the reference returns], P, iters, trace (iters, 5+L))."""
+        P = self._P(P0).copy()
+        if int(maxIters) <= 0:
+            raise UnboundLocalError("local variable 'Pt_error' referenced before assignment "
+                                    "(maxIters=0, src/calibrate.py:171)")
+        trace = np.zeros((int(maxIters), nat.TRACE_HEADER + self.L))
+        sse = ctypes.c_double(0.0)
+        iters = ctypes.c_int(0)
+        nat.check(self._lib.calib_refine(self._h, nat.dptr(P), int(maxIters), float(lamInit), float(lamMin),
+                                         float(lamMax), float(errMin), ctypes.byref(sse),
+                                         ctypes.byref(iters), nat.dptr(trace)))
+        return sse.value, P, iters.value, trace[:iters.value]
+
+    # stepping form (multi-GPU shards, benchmarks)
+    def lmBegin(self, P0, maxIters, lamInit=LAMBDA_INITIAL, lamMin=LAMBDA_MIN, lamMax=LAMBDA_MAX,
+                errMin=PT_ERROR_MIN):
+        P = self._P(P0)
+        self._lmMaxIters = int(maxIters)
+        nat.check(self._lib.calib_lm_begin(self._h, nat.dptr(P), int(maxIters), float(lamInit),
+                                           float(lamMin), float(lamMax), float(errMin)))
+
+    def reduceSize(self):
+        n = ctypes.c_int64(0)
+        nat.check(self._lib.calib_lm_reduce_size(self._h, ctypes.byref(n)))
+        return n.value
+
+    def bindReduceBuffer(self, devicePointer):
+        nat.check(self._lib.calib_lm_bind_reduce_buffer(self._h, ctypes.c_void_p(devicePointer or 0)))
+
+    def lmLocal(self):
+        nat.check(self._lib.calib_lm_local(self._h))
+
+    def lmUpdate(self):
+        nat.check(self._lib.calib_lm_update(self._h))
+
+    def lmRun(self, rounds, checkEvery=0):
+        nat.check(self._lib.calib_lm_run(self._h, int(rounds), int(checkEvery)))
+
+    def lmDone(self):
+        d = ctypes.c_int(0)
+        nat.check(self._lib.calib_lm_done(self._h, ctypes.byref(d)))
+        return bool(d.value)
+
+    def peekTrace(self, it):
+        """-> (row (5+L,), itersExecuted) of the running loop; synchronises."""
+        row = np.zeros(nat.TRACE_HEADER + self.L)
+        n = ctypes.c_int(0)
+        nat.check(self._lib.calib_lm_peek_trace(self._h, int(it), nat.dptr(row), ctypes.byref(n)))
+        return row, n.value
+
+    def lmEnd(self):
+        P = np.empty(self.K)
+        trace = np.zeros((max(self._lmMaxIters, 1), nat.TRACE_HEADER + self.L))
+        sse = ctypes.c_double(0.0)
+        iters = ctypes.c_int(0)
+        nat.check(self._lib.calib_lm_end(self._h, nat.dptr(P), ctypes.byref(sse), ctypes.byref(iters),
+                                         nat.dptr(trace)))
+        return sse.value, P, iters.value, trace[:iters.value]
+
+    # ---- profiling -----------------------------------------------------------------------
+    def profileEnable(self, on=True):
+        nat.check(self._lib.calib_profile_enable(self._h, 1 if on else 0))
+
+    def profileRead(self, which):
+        ms = ctypes.c_double(0.0)
+        n = ctypes.c_int64(0)
+        nat.check(self._lib.calib_profile_read(self._h, int(which), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+
+def distortPoints(modelId, x, k):
+    x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, 2)
+    k = np.ascontiguousarray(k, dtype=np.float64).ravel()
+    out = np.empty_like(x)
+    nat.requireDevice()
+    nat.check(nat.loadLibrary().calib_distort_points(modelId, x.shape[0], nat.dptr(x), nat.dptr(k),
+                                                     nat.dptr(out)))
+    return out
+
+
+def projectWithDistortion(modelId, A, X, k):
+    A = np.ascontiguousarray(A, dtype=np.float64).reshape(3, 3)
+    X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, 3)
+    k = np.ascontiguousarray(k, dtype=np.float64).ravel()
+    out = np.empty((X.shape[0], 2))
+    nat.requireDevice()
+    nat.check(nat.loadLibrary().calib_project_with_distortion(modelId, X.shape[0], nat.dptr(A), nat.dptr(X),
+                                                              nat.dptr(k), nat.dptr(out)))
+    return out

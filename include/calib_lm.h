@@ -1,0 +1,146 @@
+/*
+ * calib_lm.h -- C-ABI of the MI355X (gfx950) Levenberg-Marquardt refinement engine.
+ *
+ * Drop-in boundary for the nonlinear stage of pvphan/camera-calibration. The
+ * reference has no FFI layer; its seam is the duck-typed Python surface of
+ *   Calibrator.refineCalibrationParameters   src/calibrate.py:117-171
+ *   ProjectionJacobian.compute               src/jacobian.py:48-85
+ *   Calibrator.projectAllPoints              src/calibrate.py:190-197
+ *   Calibrator._computeReprojectionError     src/calibrate.py:178-188
+ *   DistortionModel.projectWithDistortion    src/distortion.py:42-59
+ * The Python host in camera-calibration_amd/ binds these entry points with
+ * ctypes (INTEGRATION.md shows the stub a maintainer adds to src/calibrate.py).
+ *
+ * Conventions
+ *  - Every function returns 0 on success, <0 on error (CALIB_E_*);
+ *    calib_last_error() returns a thread-local message. No C++ exception
+ *    crosses the boundary.
+ *  - All pointer arguments are caller-owned HOST memory unless the name ends
+ *    in _dev. The library owns all device memory of a handle.
+ *  - One handle = one GPU = one host thread (one process per GPU; shards of a
+ *    multi-GPU job are separate handles in separate processes).
+ *  - Parameter vector P (fp64, length K = L + 6*M), exactly the reference's
+ *    (src/calibrate.py:199-229):
+ *      P = (alpha, beta, gamma, uc, vc, k[0..|k|),  then per view i:
+ *           rho_x, rho_y, rho_z [DEGREES], t_x, t_y, t_z)
+ *    L = 10 radial-tangential (k1,k2,p1,p2,k3), 9 fisheye (k1..k4).
+ *  - Views are a CSR over points: view i owns points [view_offsets[i], view_offsets[i+1]).
+ */
+#ifndef CALIB_LM_H
+#define CALIB_LM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct calib_handle_s* calib_handle_t;
+
+enum { CALIB_MODEL_RADTAN = 0, CALIB_MODEL_FISHEYE = 1 };   /* src/main.py:28-33 */
+enum { CALIB_DTYPE_F64 = 0, CALIB_DTYPE_F32 = 1 };          /* storage/eval type of points, J, r;
+                                                               normal equations + solve are always fp64 */
+enum {
+    CALIB_OK = 0,
+    CALIB_E_INVALID = -1,   /* bad argument / shape (reference: ValueError, src/mathutils.py:102-105) */
+    CALIB_E_HIP = -2,       /* HIP runtime error, no device, kernel failure */
+    CALIB_E_SINGULAR = -3,  /* damped normal equations singular (reference: numpy LinAlgError, src/calibrate.py:152) */
+    CALIB_E_STATE = -4      /* call sequence error (e.g. lm_local before lm_begin) */
+};
+
+/* trace row written per LM iteration (backs shouldPrint, src/calibrate.py:158-159,269-274):
+ *   [0] iter  [1] err(P) [2] err(P+delta) [3] lambda used  [4] accepted (0/1)
+ *   [5 .. 5+L) the shared parameters of P before the update                       */
+#define CALIB_TRACE_HEADER 5
+
+int         calib_version(void);
+const char* calib_last_error(void);
+int         calib_device_count(int* out_count);
+
+int calib_create(int model, int dtype, int device_id, calib_handle_t* out_handle);
+int calib_destroy(calib_handle_t h);
+
+/* Launch all work of this handle on an existing HIP stream (e.g. the stream a
+ * torch.distributed all-reduce is ordered against). NULL = the handle's own stream. */
+int calib_set_stream(calib_handle_t h, void* hip_stream);
+
+/* Upload the correspondences once (replaces getSensorPoints' vstack, src/calibrate.py:277-282).
+ * sensor_uv: (MN,2) row-major as numpy, may be NULL (projection-only use);
+ * model_xyz: (MN,3) row-major. Packs to SoA on the device. */
+int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_offsets,
+                      const double* sensor_uv, const double* model_xyz);
+
+int calib_num_shared(calib_handle_t h, int* out_L);          /* L                          */
+int calib_num_params(calib_handle_t h, int64_t* out_K);       /* K = L + 6*num_views        */
+
+/* One evaluation at P. Any output may be NULL.
+ *   out_y   (MN,2)    projection            -> Calibrator.projectAllPoints
+ *   out_r   (MN,2)    sensor - projection   -> residual of src/calibrate.py:151
+ *   out_Jc  (MN,2,C)  compact Jacobian, C = L+6: per point rows (du, dv), columns
+ *                     [shared L | the point's own view's 6]  -> ProjectionJacobian.compute
+ *   out_sse           sum of squared residual norms -> _computeReprojectionError           */
+int calib_eval(calib_handle_t h, const double* P, double* out_y, double* out_r,
+               double* out_Jc, double* out_sse);
+
+/* Block-arrow normal equations at P (J^T J and J^T r of src/calibrate.py:146,152):
+ *   out_B (L,L), out_E (M,L,6), out_V (M,6,6), out_g (K).  Any may be NULL. */
+int calib_normal_eq(calib_handle_t h, const double* P, double* out_B, double* out_E,
+                    double* out_V, double* out_g);
+
+/* delta = (J^T J + lambda diag(J^T J))^-1 J^T r at P (src/calibrate.py:152), solved on the
+ * device through the Schur complement of the 6x6 view blocks. out_delta (K). */
+int calib_lm_step_delta(calib_handle_t h, const double* P, double lambda, double* out_delta);
+
+/* The whole refinement loop of src/calibrate.py:143-171 on the device.
+ * P_inout (K): start point in, refined parameters out.
+ * out_sse: the reference's return value = err(P) evaluated BEFORE the last update.
+ * out_trace: max_iters * (CALIB_TRACE_HEADER + L) doubles or NULL.
+ * max_iters <= 0 is CALIB_E_INVALID (the reference raises UnboundLocalError). */
+int calib_refine(calib_handle_t h, double* P_inout, int max_iters,
+                 double lam_init, double lam_min, double lam_max, double err_min,
+                 double* out_sse, int* out_iters, double* out_trace);
+
+/* ---- stepping form of the same loop (multi-GPU shards, benchmarks) ----------------
+ * One LM round = calib_lm_local (per-shard kernels, fills the reduce buffer)
+ *              -> [all-reduce(sum) of the reduce buffer across shards]
+ *              -> calib_lm_update (accept/reject, lambda, solve, back-substitute).
+ * Round 0 bootstraps (evaluates P0); rounds 1..max_iters are the LM iterations.
+ * All calls only enqueue work on the handle's stream. */
+int calib_lm_begin(calib_handle_t h, const double* P0, int max_iters,
+                   double lam_init, double lam_min, double lam_max, double err_min);
+int calib_lm_reduce_size(calib_handle_t h, int64_t* out_num_doubles);
+/* Use a caller-owned DEVICE buffer of calib_lm_reduce_size doubles as the reduce buffer
+ * (e.g. the storage of a torch tensor handed to torch.distributed.all_reduce). NULL restores
+ * the library's own buffer. */
+int calib_lm_bind_reduce_buffer(calib_handle_t h, void* reduce_dev);
+int calib_lm_local(calib_handle_t h);
+int calib_lm_update(calib_handle_t h);
+/* rounds x (local, update) without a collective (single shard). If check_every > 0 the
+ * host reads the device's done flag every check_every rounds and stops early. */
+int calib_lm_run(calib_handle_t h, int rounds, int check_every);
+int calib_lm_done(calib_handle_t h, int* out_done);           /* synchronises */
+/* Synchronise and copy trace row `iter` (CALIB_TRACE_HEADER + L doubles) of the running loop;
+ * out_iters = LM iterations executed so far (rows >= that are not written yet). */
+int calib_lm_peek_trace(calib_handle_t h, int iter, double* out_row, int* out_iters);
+/* Synchronise, return refined P (K), reference-style sse, iterations executed, trace. */
+int calib_lm_end(calib_handle_t h, double* P_out, double* out_sse, int* out_iters,
+                 double* out_trace);
+
+/* Numeric forward model on caller points (no problem needed):
+ *   calib_distort_points            DistortionModel.distortPoints          src/distortion.py:78-108,198-220
+ *   calib_project_with_distortion   DistortionModel.projectWithDistortion  src/distortion.py:42-59
+ * x_norm (N,2) normalised points; cam_xyz (N,3) camera-frame points; A (3,3) row-major. */
+int calib_distort_points(int model, int64_t n, const double* x_norm, const double* k,
+                         double* out_xd);
+int calib_project_with_distortion(int model, int64_t n, const double* A, const double* cam_xyz,
+                                  const double* k, double* out_uv);
+
+/* HIP-event timing of the two dominant kernels over the rounds enqueued since the last
+ * calib_profile_enable(h, 1). which: 0 = jacobian kernel, 1 = J^T J (MFMA) kernel. */
+int calib_profile_enable(calib_handle_t h, int on);
+int calib_profile_read(calib_handle_t h, int which, double* out_total_ms, int64_t* out_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CALIB_LM_H */

@@ -1,0 +1,231 @@
+"""HIP path (through the C-ABI) against the CPU oracle and the reference's golden vectors.
+
+Stated tolerances (fp64): projection 1e-12 relative to the pixel scale; Jacobian blocks
+1e-12 column-wise relative; normal-equation blocks 1e-11; LM step 1e-8 relative norm vs the
+reference's dense inv() step; converged intrinsics/distortion 1e-9 absolute on noise-free
+data (tests/itest_main.py:26-29), i.e. well inside the 1e-6 relative bar of BASELINE.json."""
+import numpy as np
+import pytest
+
+import camera_calibration_amd as cca
+from camera_calibration_amd import synthetic
+from conftest import loadGolden
+from oracle import calib_oracle as orc
+
+pytestmark = pytest.mark.gpu
+MODELS = [("radtan", orc.RADTAN), ("fisheye", orc.FISHEYE)]
+
+
+def colRel(a, b):
+    a = a.reshape(-1, a.shape[-1]); b = b.reshape(-1, b.shape[-1])
+    scale = np.abs(b).max(axis=0)
+    scale[scale == 0] = 1.0
+    return (np.abs(a - b).max(axis=0) / scale).max()
+
+
+def makeEngine(name, g, dtype="f64"):
+    eng = cca.RefineEngine(name, dtype, 0)
+    eng.setProblem(g["viewOffsets"], g["sensorPoints"], g["modelPoints"])
+    return eng
+
+
+@pytest.mark.parametrize("name,model", MODELS)
+def test_eval_vs_oracle_and_reference(name, model):
+    g = loadGolden(f"g2_config1_{name}.npz")
+    offs, s, m, P0 = g["viewOffsets"], g["sensorPoints"], g["modelPoints"], g["P0"]
+    eng = makeEngine(name, g)
+    ev = eng.evaluate(P0, wantY=True, wantR=True, wantJ=True)
+    yo = orc.projectAllPoints(model, P0, offs, m)
+    assert np.abs(ev["y"] - yo).max() < 1e-12 * 1500
+    assert np.abs(ev["y"] - g["y0"]).max() < 1e-12 * 1500          # the reference's own projection
+    assert np.abs(ev["r"] - (s - yo)).max() < 1e-12 * 1500
+    assert abs(ev["sse"] - g["err0"]) < 1e-11 * g["err0"]
+    Jo = orc.jacobianCompact(model, P0, offs, m)
+    assert colRel(ev["Jc"], Jo) < 1e-12
+    # dense layout of ProjectionJacobian.compute vs the reference's dense J
+    jac = cca.ProjectionJacobian({"radtan": cca.RadialTangentialModel, "fisheye": cca.FisheyeModel}[name]())
+    views = [m[a:b] for a, b in zip(offs[:-1], offs[1:])]
+    J = jac.compute(P0.reshape(-1, 1), views)
+    assert J.shape == g["J"].shape
+    assert np.abs(J - g["J"]).max() / np.abs(g["J"]).max() < 1e-13
+    assert J[0, eng.L + 6] == 0            # tests/test_jacobian.py:70
+    eng.close()
+
+
+@pytest.mark.parametrize("name,model", MODELS)
+def test_jacobian_blocks_vs_reference_golden(name, model):
+    g = loadGolden("g1_blocks.npz")
+    jac = cca.ProjectionJacobian({"radtan": cca.RadialTangentialModel, "fisheye": cca.FisheyeModel}[name]())
+    intr = g[f"{name}_intr"]
+    for j in range(4):
+        mp, ext = g[f"{name}_modelPoints"][j], g[f"{name}_ext"][j]
+        JI = jac._createIntrinsicsJacobianBlock(intr, ext, mp)
+        JE = jac._createExtrinsicsJacobianBlock(intr, ext, mp)
+        assert JI.shape == (2 * mp.shape[0], intr.shape[0]) and JE.shape == (2 * mp.shape[0], 6)
+        assert colRel(JI, g[f"{name}_JI"][j]) < 1e-12
+        assert colRel(JE, g[f"{name}_JE"][j]) < 1e-12
+
+
+def test_zero_parameter_case_no_nan():
+    # tests/test_jacobian.py:19-24,42-56
+    g = loadGolden("g1_blocks.npz")
+    jac = cca.createJacRadTan()
+    JI = jac._createIntrinsicsJacobianBlock(g["zero_intr"], g["zero_ext"], g["zero_modelPoints"])
+    JE = jac._createExtrinsicsJacobianBlock(g["zero_intr"], g["zero_ext"], g["zero_modelPoints"])
+    assert JI.shape == (4, 10) and JE.shape == (4, 6)
+    assert not np.isnan(JI).any() and not np.isnan(JE).any() and np.abs(JI).sum() > 0
+    assert np.abs(JI - g["zero_JI"]).max() < 1e-11 and np.abs(JE - g["zero_JE"]).max() < 1e-10
+
+
+@pytest.mark.parametrize("tag,name,model", [("g2_config1_radtan.npz", "radtan", orc.RADTAN),
+                                            ("g2_config1_fisheye.npz", "fisheye", orc.FISHEYE),
+                                            ("g3_unittest15.npz", "radtan", orc.RADTAN)])
+def test_normal_equations_and_step(tag, name, model):
+    g = loadGolden(tag)
+    offs, s, m, P0 = g["viewOffsets"], g["sensorPoints"], g["modelPoints"], g["P0"]
+    L = orc.numShared(model)
+    eng = makeEngine(name, g)
+    B, E, V, gg = eng.normalEquations(P0)
+    JTJ, JTr = g["JTJ"], g["JTr"]                                   # from the reference's dense J
+    assert np.abs(B - JTJ[:L, :L]).max() / np.abs(JTJ[:L, :L]).max() < 1e-11
+    for i in range(eng.M):
+        c = L + 6 * i
+        assert np.abs(V[i] - JTJ[c:c + 6, c:c + 6]).max() / np.abs(JTJ[c:c + 6, c:c + 6]).max() < 1e-11
+        assert np.abs(E[i] - JTJ[:L, c:c + 6]).max() / np.abs(JTJ[:L, c:c + 6]).max() < 1e-11
+    assert np.abs(gg - JTr).max() / np.abs(JTr).max() < 1e-11
+    d = eng.stepDelta(P0, 1e-3)
+    assert np.linalg.norm(d - g["delta"]) / np.linalg.norm(g["delta"]) < 1e-8      # reference's inv() step
+    do = orc.lmStepSchur(model, P0, offs, s, m, 1e-3)
+    assert np.linalg.norm(d - do) / np.linalg.norm(do) < 1e-9
+    eng.close()
+
+
+@pytest.mark.parametrize("tag,name,model", [("g2_config1_radtan.npz", "radtan", orc.RADTAN),
+                                            ("g2_config1_fisheye.npz", "fisheye", orc.FISHEYE),
+                                            ("g3_unittest15.npz", "radtan", orc.RADTAN),
+                                            ("g4_realistic.npz", "radtan", orc.RADTAN)])
+def test_refine_matches_reference_result(tag, name, model):
+    g = loadGolden(tag)
+    P0 = g["P0"]
+    eng = makeEngine(name, g)
+    sse, P, iters, trace = eng.refine(P0, int(g["maxIters"]))
+    ref = g["traceIterErrLam"]
+    assert sse < 1e-7 and g["sseFinal"] < 1e-7
+    L = eng.L
+    assert np.abs(P[:L] - g["Pfinal"][:L]).max() < 1e-9, "A, k differ from the reference's result"
+    A, W, k = orc.decomposeParameterVector(P, model)
+    assert np.abs(W - g["Wfinal"]).max() < 1e-8
+    # well-separated early iterations follow the reference's lambda / error trace
+    n = min(5, iters, ref.shape[0])
+    assert np.array_equal(trace[:n, 3], ref[:n, 2])
+    assert np.allclose(np.minimum(trace[:n, 1], trace[:n, 2]), ref[:n, 1], rtol=1e-6)
+    assert abs(iters - ref.shape[0]) <= 3
+    eng.close()
+
+
+def test_refine_ragged200_vs_oracle():
+    g = loadGolden("g5_ragged200.npz")
+    offs, s, m, P0 = g["viewOffsets"], g["sensorPoints"], g["modelPoints"], g["P0"]
+    eng = makeEngine("radtan", g)
+    d = eng.stepDelta(P0, float(g["lam"]))
+    assert np.linalg.norm(d - g["delta"]) / np.linalg.norm(g["delta"]) < 1e-8
+    sse, P, iters, trace = eng.refine(P0, 50)
+    sseO, PO, traceO = orc.refineSchur(orc.RADTAN, P0, offs, s, m, 50)
+    assert sse < 1e-9 and sseO < 1e-9
+    assert np.abs(P[:10] - PO[:10]).max() < 1e-9
+    assert np.abs(P[:10] - g["Ptrue"][:10]).max() < 1e-9
+    assert np.abs(P - PO).max() < 1e-7
+    eng.close()
+
+
+def test_calibrator_dropin_surface():
+    # the reference's own hot-path tests, against the drop-in (tests/test_calibrate.py:80-133)
+    g = loadGolden("g3_unittest15.npz")
+    offs = g["viewOffsets"]
+    dets = [(g["sensorPoints"][a:b], g["modelPoints"][a:b]) for a, b in zip(offs[:-1], offs[1:])]
+    cal = cca.Calibrator(cca.RadialTangentialModel())
+    Ptrue = cal._composeParameterVector(g["Atrue"], list(g["Wtrue"]), tuple(g["ktrue"]))
+    assert cal._computeReprojectionError(Ptrue, dets) == pytest.approx(0, abs=1e-7)
+    y = cal.projectAllPoints(Ptrue, [m for s, m in dets])
+    assert y.shape == (offs[-1], 2)
+    assert np.abs(y - g["sensorPoints"]).max() < 1e-9
+    sse, A, W, k = cal.refineCalibrationParameters(g["A0"], list(g["W0"]), tuple(g["k0"]), dets, 100)
+    assert isinstance(sse, float) and A.shape == (3, 3) and len(W) == 15 and len(k) == 5
+    assert np.allclose(A, g["Afinal"], atol=1e-9) and np.allclose(k, g["kfinal"], atol=1e-9)
+    # re-entrant use with maxIters=1 (src/animate.py:40-42): lambda restarts at 1e-3 each call
+    sse1, A1, W1, k1 = cal.refineCalibrationParameters(g["A0"], list(g["W0"]), tuple(g["k0"]), dets, 1)
+    assert sse1 == pytest.approx(float(g["err0"]), rel=1e-10)       # pre-update error is returned
+    assert cal.lastTrace.shape == (1, 15) and cal.lastTrace[0, 3] == 1e-3
+
+
+def test_forward_model_helpers():
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-0.6, 0.6, (100, 2))
+    X = np.column_stack((x * 1.3, np.full(100, 1.3)))
+    for name, model, cls in (("radtan", orc.RADTAN, cca.RadialTangentialModel), ("fisheye", orc.FISHEYE, cca.FisheyeModel)):
+        k = synthetic.CONFIGS["c2" if name == "radtan" else "c3"]["k"]
+        A = synthetic.CONFIGS["c2" if name == "radtan" else "c3"]["A"]
+        xd = cls().distortPoints(x, k)
+        xo, yo = orc.distortPoints(model, x[:, 0], x[:, 1], k)
+        assert np.abs(xd - np.stack((xo, yo), 1)).max() < 1e-14
+        uv = cls().projectWithDistortion(A, X, k)
+        assert np.abs(uv[:, 0] - (A[0, 0] * xo + A[0, 1] * yo + A[0, 2])).max() < 1e-11
+    with pytest.raises(ValueError):
+        cca.RadialTangentialModel().distortPoints(np.zeros((3, 3)), (0,) * 5)
+    # fisheye on the optical axis: the reference yields NaN (0/0); the engine returns the limit
+    uv = cca.FisheyeModel().projectWithDistortion(synthetic.FISHEYE_A, np.array([[0.0, 0.0, 1.0]]), synthetic.FISHEYE_K)
+    assert np.allclose(uv, [[700.5, 529.2]])
+
+
+def test_edge_cases():
+    g = loadGolden("g2_config1_radtan.npz")
+    offs, s, m, P0 = g["viewOffsets"], g["sensorPoints"], g["modelPoints"], g["P0"]
+    eng = makeEngine("radtan", g)
+    with pytest.raises(UnboundLocalError):
+        eng.refine(P0, 0)                              # src/calibrate.py:171 with maxIters=0
+    with pytest.raises(ValueError):
+        eng.evaluate(P0[:-1])
+    # an empty view in the middle: projection works, refinement is singular
+    offs2 = np.concatenate((offs[:4], [offs[3]], offs[4:]))
+    P2 = np.concatenate((P0[:10 + 18], [10, 20, 30, 0, 0, 1.0], P0[10 + 18:]))
+    eng2 = cca.RefineEngine("radtan")
+    eng2.setProblem(offs2, s, m)
+    ev = eng2.evaluate(P2, wantY=True)
+    assert np.abs(ev["y"] - g["y0"]).max() < 1e-9
+    with pytest.raises(np.linalg.LinAlgError):
+        eng2.refine(P2, 5)
+    # a view with 2 points only (rank-deficient 6x6 block)
+    offs3 = np.array([0, 2, 56], dtype=np.int64)
+    eng3 = cca.RefineEngine("radtan")
+    eng3.setProblem(offs3, s[:56], m[:56])
+    with pytest.raises(np.linalg.LinAlgError):
+        eng3.refine(np.concatenate((P0[:10], P0[10:16], P0[10:16])), 5)
+    # empty problem
+    eng4 = cca.RefineEngine("radtan")
+    eng4.setProblem(np.zeros(1, dtype=np.int64), np.empty((0, 2)), np.empty((0, 3)))
+    assert eng4.evaluate(P0[:10], wantY=True)["y"].shape == (0, 2)
+    for e in (eng, eng2, eng3, eng4):
+        e.close()
+
+
+def test_one_big_view_spans_many_gram_items():
+    # a single view with 3000 points (> kGramChunk and > one tile) vs the oracle
+    rng = np.random.default_rng(5)
+    corners = np.column_stack((rng.uniform(0, 0.4, 3000), rng.uniform(0, 0.3, 3000), rng.uniform(-0.01, 0.01, 3000)))
+    g = loadGolden("g2_config1_radtan.npz")
+    P = np.concatenate((g["Pfinal"][:10], g["Pfinal"][10:16]))
+    offs = np.array([0, 3000], dtype=np.int64)
+    s = orc.projectAllPoints(orc.RADTAN, P, offs, corners) + rng.normal(0, 0.05, (3000, 2))
+    P0 = P * (1 + 1e-3 * rng.standard_normal(16))
+    eng = cca.RefineEngine("radtan")
+    eng.setProblem(offs, s, corners)
+    B, E, V, gg = eng.normalEquations(P0)
+    Jc = orc.jacobianCompact(orc.RADTAN, P0, offs, corners)
+    Bo, Eo, Vo, go = orc.normalBlocks(orc.RADTAN, Jc, s - orc.projectAllPoints(orc.RADTAN, P0, offs, corners), offs)
+    assert np.abs(B - Bo).max() / np.abs(Bo).max() < 1e-11
+    assert np.abs(V - Vo).max() / np.abs(Vo).max() < 1e-11
+    assert np.abs(gg - go).max() / np.abs(go).max() < 1e-10
+    d = eng.stepDelta(P0, 1e-3)
+    do = orc.lmStepSchur(orc.RADTAN, P0, offs, s, corners, 1e-3)
+    assert np.linalg.norm(d - do) / np.linalg.norm(do) < 1e-8
+    eng.close()

@@ -1,0 +1,83 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/calib_lm.h
+declares, host packing / pose helpers agree with the reference's golden vectors, and the
+product path refuses to run without a GPU (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import camera_calibration_amd as cca
+from camera_calibration_amd import _native as nat
+from camera_calibration_amd import engine, mathutils as mu, synthetic
+from conftest import ROOT, loadGolden
+
+
+def headerSymbols():
+    text = open(os.path.join(ROOT, "include", "calib_lm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(calib_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = nat.loadLibrary()
+    names = headerSymbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/calib_lm.h but not exported"
+    assert sorted(nat.SIGNATURES) == names, "ctypes binding and header disagree"
+    assert lib.calib_version() >= 100
+
+
+def test_no_cpu_fallback_without_device():
+    if nat.deviceCount() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(nat.CalibNativeError):
+        cca.RefineEngine("radtan")
+    with pytest.raises(nat.CalibNativeError):
+        cca.RadialTangentialModel().distortPoints(np.zeros((2, 2)), (0, 0, 0, 0, 0))
+
+
+def test_pose_helpers_vs_reference_known_answers():
+    g = loadGolden("g0_mathutils.npz")
+    assert np.abs(mu.eulerToRotationMatrices(g["angles"]) - g["R"]).max() < 1e-15
+    assert np.abs(mu.rotationMatricesToEuler(g["R"]) - g["eulerBack"]).max() < 1e-12
+    assert np.abs(np.array(mu.rotationMatrixToEuler(g["R"][3])) - g["eulerBack"][3]).max() < 1e-12
+
+
+def test_compose_decompose_roundtrip_vs_golden():
+    # tests/test_calibrate.py:63-78
+    g = loadGolden("g3_unittest15.npz")
+    cal = cca.Calibrator(cca.RadialTangentialModel())
+    P = cal._composeParameterVector(g["Atrue"], list(g["Wtrue"]), tuple(g["ktrue"]))
+    assert P.shape == (6 * 15 + 10, 1)
+    assert np.abs(P.ravel() - g["Ptrue"]).max() < 1e-12
+    A, W, k = cal._decomposeParameterVector(P)
+    assert np.allclose(A, g["Atrue"], atol=1e-9)
+    assert np.allclose(np.array(W), g["Wtrue"], atol=1e-9)
+    assert np.allclose(k, g["ktrue"], atol=1e-9)
+    assert len(W) == 15 and W[0].shape == (4, 4)
+
+
+def test_pack_detections_and_sensor_points():
+    g = loadGolden("g3_unittest15.npz")
+    offs = g["viewOffsets"]
+    dets = [(g["sensorPoints"][a:b], g["modelPoints"][a:b]) for a, b in zip(offs[:-1], offs[1:])]
+    o2, s2, m2 = engine.packDetections(dets)
+    assert np.array_equal(o2, offs) and np.array_equal(s2, g["sensorPoints"]) and np.array_equal(m2, g["modelPoints"])
+    assert np.array_equal(cca.getSensorPoints(dets), g["sensorPoints"])
+    assert cca.getSensorPoints([]).shape == (0, 2)
+    with pytest.raises(ValueError):
+        engine.packDetections([(np.zeros((3, 2)), np.zeros((4, 3)))])
+
+
+def test_synthetic_pose_sampler_vs_reference_dataset():
+    g = loadGolden("g6_generator.npz")
+    for tag in ("c2", "c3", "c5"):
+        corners = synthetic.checkerboardCorners(*synthetic.CONFIGS[tag]["board"])
+        assert np.array_equal(corners, g[f"{tag}_corners"])
+        W = synthetic.sampleBoardPosesInCamera(corners, np.arange(12))
+        assert np.abs(W - g[f"{tag}_W"]).max() < 1e-13
+        # any sub-range gives the same poses (global view index)
+        W2 = synthetic.sampleBoardPosesInCamera(corners, np.arange(5, 9))
+        assert np.array_equal(W2, W[5:9])
