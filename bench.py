@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Benchmark of the LM refinement hot path (BASELINE.json metric: LM iterations/s and
+point-residuals/s on a synthetic checkerboard dataset).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = ONE LM iteration (src/calibrate.py:143-168) over the rank's resident views:
+per-point residual + Jacobian kernel, J^T J / J^T r MFMA kernel, per-view Schur
+elimination, (N > 1: one RCCL all-reduce of the reduce buffer), accept/reject + L x L
+solve, back-substitution. Termination tests are disabled for the timed region
+(lam_min = 0, lam_max = inf, err_min = -inf) so that exactly K iterations execute, each
+with full work. Weak scaling: every rank holds `views` views of the config.
+One JSON line is printed by rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_MATRIX_PEAK_TFLOPS = 78.6  # public MI355X sheet; fp64 MFMA = fp64 vector rate
+
+
+def algorithmicBytesPerPoint(L, wordBytes):
+    """jacobian kernel reads (u,v,X,Y,Z) = 5w, writes the 2 x C block = 2Cw and
+    r = 2w -> (7 + 2C) w. gram kernel reads (2C + 2) w."""
+    C = L + 6
+    return (7 + 2 * C) * wordBytes, (2 * C + 2) * wordBytes
+
+
+def cpuBaseline(shard, cfgName, seconds=20.0):
+    """The oracle (numpy restatement of the reference algorithm: dense J, dense J^T J, explicit
+    inv) timed on this box's host cores, on a bounded sample of the same workload."""
+    from oracle import calib_oracle as orc
+    model = orc.RADTAN if shard["model"] == "radtan" else orc.FISHEYE
+    N = shard["pointsPerView"]
+    views = max(4, min(150, 30000 // N))
+    offs = shard["viewOffsets"][:views + 1]
+    n = int(offs[-1])
+    s, m = shard["sensorPoints"][:n], shard["modelPoints"][:n]
+    L = orc.numShared(model)
+    P0 = np.concatenate((shard["P0"][:L], shard["P0"][L:L + 6 * views]))
+    iters = 2
+    t0 = time.perf_counter()
+    orc.refineDense(model, P0, offs, s, m, iters, lamMin=0.0, lamMax=np.inf, errMin=-np.inf)
+    tDense = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    orc.refineSchur(model, P0, offs, s, m, iters, lamMin=0.0, lamMax=np.inf, errMin=-np.inf)
+    tSchur = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count()
+    return {
+        "value": n * iters / tDense, "unit": "point-residuals/s", "cores": int(threads), "kind": "port",
+        "sample": f"first {views} views x {N} pts of {cfgName} ({n} points), {iters} LM iterations of "
+                  f"the reference's dense algorithm (dense J, J.T@J, inv) restated in numpy "
+                  f"(oracle.refineDense), {tDense:.1f} s; BLAS uses {threads} threads, the rest is 1 thread",
+        "schur_form_value": n * iters / tSchur,
+        "schur_form_note": f"same sample through the block-arrow/Schur numpy oracle, {tSchur:.2f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", help="c2 | c3 | c4 | c5 (BASELINE.json configs[1..4])")
+    ap.add_argument("--views", type=int, default=None, help="views per GPU (default: the config's)")
+    ap.add_argument("--noise", type=float, default=0.1, help="sensor noise sigma in px")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    import torch
+    import camera_calibration_amd as cca
+    from camera_calibration_amd import distributed, synthetic
+
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    cfg = dict(synthetic.CONFIGS[args.workload])
+    viewsPerGpu = args.views or cfg["views"]
+    if args.workload == "c5" and args.views is None:
+        viewsPerGpu = cfg["views"] // 8      # the config is stated for 8 GPUs
+    if args.workload == "c4" and args.views is None:
+        viewsPerGpu = cfg["views"] // 8
+    t0 = time.perf_counter()
+    shard = synthetic.makeShard(cfg, viewStart=rank * viewsPerGpu, numViews=viewsPerGpu,
+                                noiseSigma=args.noise, device=local)
+    tGen = time.perf_counter() - t0
+    MNlocal = int(shard["viewOffsets"][-1])
+
+    eng = cca.RefineEngine(cfg["model"], cfg["dtype"], local)
+    t0 = time.perf_counter()
+    eng.setProblem(shard["viewOffsets"], shard["sensorPoints"], shard["modelPoints"])
+    tUpload = time.perf_counter() - t0
+    lmOpts = dict(lamInit=1e-3, lamMin=0.0, lamMax=float("inf"), errMin=-float("inf"))
+    total = args.warmup + args.steps
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.lmDone()        # synchronises the engine's stream (its own stream when N == 1)
+
+    if world > 1:
+        allReduce = distributed.torchAllReduce(eng, torch.device("cuda", local))
+        lm = distributed.ShardedLM(eng, allReduce)
+        lm.begin(shard["P0"], total, **lmOpts)
+        runRounds = lm.run
+    else:
+        eng.lmBegin(shard["P0"], total, **lmOpts)
+        eng.lmRun(1)
+        runRounds = eng.lmRun
+    runRounds(args.warmup)
+    barrier()
+    eng.profileEnable(True)
+    t0 = time.perf_counter()
+    runRounds(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    jacMs, jacN = eng.profileRead(0)
+    gramMs, gramN = eng.profileRead(1)
+    eng.profileEnable(False)
+    sse, P, iters, trace = eng.lmEnd()
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        n = torch.tensor([MNlocal], dtype=torch.int64, device="cuda")
+        dist.all_reduce(n)
+        MNglobal = int(n.item())
+    else:
+        MNglobal = MNlocal
+
+    if rank == 0:
+        L = eng.L
+        w = 8 if cfg["dtype"] == "f64" else 4
+        jacBytes, gramBytes = algorithmicBytesPerPoint(L, w)
+        jacAvgMs = jacMs / max(jacN, 1)
+        gramAvgMs = gramMs / max(gramN, 1)
+        jacGBs = jacBytes * MNlocal / (jacAvgMs * 1e-3) / 1e9 if jacN else None
+        gramGBs = gramBytes * MNlocal / (gramAvgMs * 1e-3) / 1e9 if gramN else None
+        C = L + 6
+        gramFlops = (4 * 16 * 16 + 4 * C) * MNlocal      # as executed on full 16x16 MFMA tiles + J^T r
+        accepted = int(trace[args.warmup:, 4].sum()) if trace.shape[0] > args.warmup else 0
+        traffic = None
+        trafficFile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(trafficFile):
+            try:
+                traffic = json.load(open(trafficFile)).get(args.workload, {}).get("jacobian_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "LM point-residuals/sec (and LM iters/sec), synthetic checkerboard, views sharded over GPUs",
+            "value": MNglobal * args.steps / elapsed,
+            "unit": "point-residuals/s",
+            "lm_iters_per_s": args.steps / elapsed,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": cfg["dtype"], "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {viewsPerGpu} views x {shard['pointsPerView']} pts per GPU, "
+                                   f"{cfg['model']}, {cfg['dtype']}, sensor noise {args.noise} px",
+                       "views_per_gpu": viewsPerGpu, "points_per_view": shard["pointsPerView"],
+                       "global_points": MNglobal, "model": cfg["model"], "parallelism": f"views-sharded x{world}"},
+            "roofline": {"kernel": "jacobian_kernel", "bound": "hbm",
+                         "achieved": jacGBs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (jacGBs / HBM_PEAK_GBS) if jacGBs else None, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": jacBytes * MNlocal,
+                         "avg_launch_ms": jacAvgMs, "launches_timed": jacN},
+            "roofline_gram": {"kernel": "gram_kernel (v_mfma_f64_16x16x4_f64)", "bound": "hbm",
+                              "achieved": gramGBs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": (gramGBs / HBM_PEAK_GBS) if gramGBs else None,
+                              "mfma_tflops": gramFlops / (gramAvgMs * 1e-3) / 1e12 if gramN else None,
+                              "mfma_peak_tflops": FP64_MATRIX_PEAK_TFLOPS,
+                              "mfma_util": gramFlops / (gramAvgMs * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS if gramN else None,
+                              "avg_launch_ms": gramAvgMs, "launches_timed": gramN},
+            "lm": {"accepted_steps_in_timed_region": accepted, "final_sse": sse,
+                   "max_rel_err_intrinsics_vs_truth": float(np.max(np.abs(P[:L] - shard["Ptrue"][:L])
+                                                                   / np.maximum(np.abs(shard["Ptrue"][:L]), 1.0)))},
+            "setup_s": {"generate": tGen, "pack_upload": tUpload},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpuBaseline(shard, args.workload)
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,90 @@
+"""Views sharded over the GPUs of one node: one process per GPU, one all-reduce per LM step.
+
+Rows of J belonging to different views are independent given P, and a view's six
+extrinsics appear only in its own rows (src/jacobian.py:81-83), so each rank keeps a
+contiguous range of views resident in its HBM and eliminates their 6x6 blocks locally.
+What is shared is the L x L Schur system: per LM round every rank contributes its partial
+sums (reduce buffer of calib_lm.h, 443 doubles for L = 10) to ONE sum all-reduce (RCCL over
+xGMI through torch.distributed), after which every rank takes the identical accept/reject
+decision and solves the identical L x L system redundantly. No other data-path collective.
+
+The driver is generic over the shard engine (RefineEngine on the GPU; tests drive the
+same code with a CPU test double over gloo).
+"""
+import numpy as np
+
+
+def partitionViews(viewOffsets, worldSize):
+    """Contiguous view ranges balanced by point count.
+    -> list of (viewStart, viewEnd) per rank (possibly empty ranges when M < worldSize)."""
+    offs = np.asarray(viewOffsets, dtype=np.int64)
+    M = offs.shape[0] - 1
+    total = int(offs[-1])
+    bounds = [0]
+    for r in range(1, worldSize):
+        target = total * r / worldSize
+        v = int(np.searchsorted(offs, target, side="left"))
+        # pick the boundary whose point offset is closest to the target
+        if v > 0 and abs(int(offs[v - 1]) - target) <= abs(int(offs[min(v, M)]) - target):
+            v -= 1
+        v = min(max(v, bounds[-1]), M)
+        bounds.append(v)
+    bounds.append(M)
+    return [(bounds[r], bounds[r + 1]) for r in range(worldSize)]
+
+
+def shardProblem(P, viewOffsets, sensorPoints, modelPoints, L, viewRange):
+    """Cut one rank's views out of a global problem -> (P_local, offsets_local, sensor, model)."""
+    v0, v1 = viewRange
+    offs = np.asarray(viewOffsets, dtype=np.int64)
+    a, b = int(offs[v0]), int(offs[v1])
+    P = np.asarray(P, dtype=np.float64).ravel()
+    Pl = np.concatenate((P[:L], P[L + 6 * v0:L + 6 * v1]))
+    sensor = None if sensorPoints is None else np.asarray(sensorPoints)[a:b]
+    return Pl, offs[v0:v1 + 1] - a, sensor, np.asarray(modelPoints)[a:b]
+
+
+class ShardedLM:
+    """One rank of a sharded LM run: engine.lmLocal -> allReduce -> engine.lmUpdate per round."""
+
+    def __init__(self, eng, allReduce):
+        self.eng = eng
+        self.allReduce = allReduce      # callable(): sums the bound reduce buffer over ranks, in place
+        self.maxIters = 0
+
+    def begin(self, Plocal, maxIters, **lmOptions):
+        self.maxIters = int(maxIters)
+        self.eng.lmBegin(Plocal, maxIters, **lmOptions)
+        self.round()                    # round 0: evaluate P0, first step
+
+    def round(self):
+        self.eng.lmLocal()
+        self.allReduce()
+        self.eng.lmUpdate()
+
+    def run(self, rounds, checkEvery=0):
+        """`rounds` LM iterations; with checkEvery > 0 the (replicated, hence identical on every
+        rank) done flag is read every checkEvery rounds and the loop stops early."""
+        for i in range(int(rounds)):
+            self.round()
+            if checkEvery > 0 and (i + 1) % checkEvery == 0 and i + 1 < rounds and self.eng.lmDone():
+                break
+
+    def end(self):
+        return self.eng.lmEnd()
+
+
+def torchAllReduce(eng, device):
+    """Bind a float64 CUDA tensor as the engine's reduce buffer and order the engine's kernels on
+    torch's current stream, so torch.distributed.all_reduce (RCCL) needs no host sync."""
+    import torch
+    import torch.distributed as dist
+    buf = torch.zeros(eng.reduceSize(), dtype=torch.float64, device=device)
+    eng.setStream(torch.cuda.current_stream(device).cuda_stream)
+    eng.bindReduceBuffer(buf.data_ptr())
+
+    def allReduce():
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+
+    allReduce.buffer = buf      # keep the storage alive
+    return allReduce
