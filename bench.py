@@ -161,10 +161,13 @@ def main():
         jacBytes, gramBytes = algorithmicBytesPerPoint(L, w)
         jacAvgMs = jacMs / max(jacN, 1)
         gramAvgMs = gramMs / max(gramN, 1)
-        jacGBs = jacBytes * MNlocal / (jacAvgMs * 1e-3) / 1e9 if jacN else None
-        gramGBs = gramBytes * MNlocal / (gramAvgMs * 1e-3) / 1e9 if gramN else None
+        # a launch covers one chunk of whole views: points per launch = points x steps / launches
+        jacPts = MNlocal * args.steps / max(jacN, 1)
+        gramPts = MNlocal * args.steps / max(gramN, 1)
+        jacGBs = jacBytes * jacPts / (jacAvgMs * 1e-3) / 1e9 if jacN else None
+        gramGBs = gramBytes * gramPts / (gramAvgMs * 1e-3) / 1e9 if gramN else None
         C = L + 6
-        gramFlops = (4 * 16 * 16 + 4 * C) * MNlocal      # as executed on full 16x16 MFMA tiles + J^T r
+        gramFlops = (4 * 16 * 16 + 4 * C) * gramPts      # as executed on full 16x16 MFMA tiles + J^T r
         accepted = int(trace[args.warmup:, 4].sum()) if trace.shape[0] > args.warmup else 0
         traffic = None
         trafficFile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -189,7 +192,8 @@ def main():
             "roofline": {"kernel": "jacobian_kernel", "bound": "hbm",
                          "achieved": jacGBs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (jacGBs / HBM_PEAK_GBS) if jacGBs else None, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": jacBytes * MNlocal,
+                         "algorithmic_bytes_per_launch": jacBytes * jacPts, "points_per_launch": jacPts,
+                         "launches_per_step": jacN / args.steps,
                          "avg_launch_ms": jacAvgMs, "launches_timed": jacN},
             "roofline_gram": {"kernel": "gram_kernel (v_mfma_f64_16x16x4_f64)", "bound": "hbm",
                               "achieved": gramGBs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -197,6 +201,7 @@ def main():
                               "mfma_tflops": gramFlops / (gramAvgMs * 1e-3) / 1e12 if gramN else None,
                               "mfma_peak_tflops": FP64_MATRIX_PEAK_TFLOPS,
                               "mfma_util": gramFlops / (gramAvgMs * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS if gramN else None,
+                              "points_per_launch": gramPts, "launches_per_step": gramN / args.steps,
                               "avg_launch_ms": gramAvgMs, "launches_timed": gramN},
             "lm": {"accepted_steps_in_timed_region": accepted, "final_sse": sse,
                    "max_rel_err_intrinsics_vs_truth": float(np.max(np.abs(P[:L] - shard["Ptrue"][:L])

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -53,7 +54,7 @@ struct DevBuf {
     }
 };
 
-constexpr int kEventPool = 4096;
+constexpr int kEventPool = 32768;
 
 }  // namespace
 
@@ -71,6 +72,12 @@ struct calib_handle_s {
     int64_t n_tiles = 0;
     int max_views_per_tile = 1;
     int schur_blocks = 1;
+    int gram_wpi = 1;             // waves per gram item
+    // LM rounds walk the points in chunks of whole views so that a chunk's compact J
+    // (written by the jacobian kernel, read once by the gram kernel) can stay on-die
+    struct Chunk { int64_t p0, p1; int item0, item1; };
+    std::vector<Chunk> chunks;
+    int64_t max_chunk_points = 0;
     DevBuf<unsigned char> uv, XY, Z, VC, J, r, y;   // typed by dtype
     DevBuf<int> pt_view, view_ext, item_n, view_item0;
     DevBuf<int64_t> item_pt0;
@@ -118,65 +125,70 @@ int launch_view_setup(calib_handle_s* h, const double* P0, const double* P1, con
 
 template <int MODEL, typename T>
 int launch_jacobian_t(calib_handle_s* h, const double* P0, const double* P1, const LMState* st, int sel,
-                      bool wantJ, bool wantR, bool wantY) {
+                      bool wantJ, bool wantR, bool wantY, bool wantSse, int64_t p_begin, int64_t p_end) {
     using T2 = typename Pair<T>::type;
-    if (h->MN == 0) return CALIB_OK;
+    if (p_end <= p_begin) return CALIB_OK;
     JacArgs<T> a;
     a.P0 = P0; a.P1 = P1; a.st = st; a.sel = sel;
     a.uv = reinterpret_cast<const T2*>(h->uv.p);
     a.XY = reinterpret_cast<const T2*>(h->XY.p);
     a.Z = reinterpret_cast<const T*>(h->Z.p);
     a.pt_view = h->pt_view.p;
-    a.MN = h->MN;
+    a.p_begin = p_begin;
+    a.p_end = p_end;
     a.VC = reinterpret_cast<const T*>(h->VC.p);
     a.J = wantJ ? reinterpret_cast<T2*>(h->J.p) : nullptr;
     a.r = wantR ? reinterpret_cast<T2*>(h->r.p) : nullptr;
     a.y = wantY ? reinterpret_cast<T2*>(h->y.p) : nullptr;
-    a.sse_part = h->sse_part.p;
+    a.sse_part = wantSse ? h->sse_part.p : nullptr;
     const size_t lds = 32 + (size_t)h->max_views_per_tile * kViewStride * sizeof(T);
     int pi = prof_begin(h, 0);
-    hipLaunchKernelGGL((jacobian_kernel<MODEL, T>), dim3((unsigned)h->n_tiles), dim3(kTile), lds, h->stream, a);
+    const unsigned tiles = (unsigned)((p_end - p_begin + kTile - 1) / kTile);
+    hipLaunchKernelGGL((jacobian_kernel<MODEL, T>), dim3(tiles), dim3(kTile), lds, h->stream, a);
     prof_end(h, pi);
     HIP_TRY(hipGetLastError());
     return CALIB_OK;
 }
 
 int launch_jacobian(calib_handle_s* h, const double* P0, const double* P1, const LMState* st, int sel,
-                    bool wantJ, bool wantR, bool wantY) {
+                    bool wantJ, bool wantR, bool wantY, bool wantSse, int64_t p_begin, int64_t p_end) {
     if (h->dtype == CALIB_DTYPE_F64) {
-        int rc = launch_view_setup<double>(h, P0, P1, st, sel);
-        if (rc) return rc;
         return h->model == CALIB_MODEL_RADTAN
-                   ? launch_jacobian_t<kRadtan, double>(h, P0, P1, st, sel, wantJ, wantR, wantY)
-                   : launch_jacobian_t<kFisheye, double>(h, P0, P1, st, sel, wantJ, wantR, wantY);
+                   ? launch_jacobian_t<kRadtan, double>(h, P0, P1, st, sel, wantJ, wantR, wantY, wantSse, p_begin, p_end)
+                   : launch_jacobian_t<kFisheye, double>(h, P0, P1, st, sel, wantJ, wantR, wantY, wantSse, p_begin, p_end);
     }
-    int rc = launch_view_setup<float>(h, P0, P1, st, sel);
-    if (rc) return rc;
     return h->model == CALIB_MODEL_RADTAN
-               ? launch_jacobian_t<kRadtan, float>(h, P0, P1, st, sel, wantJ, wantR, wantY)
-               : launch_jacobian_t<kFisheye, float>(h, P0, P1, st, sel, wantJ, wantR, wantY);
+               ? launch_jacobian_t<kRadtan, float>(h, P0, P1, st, sel, wantJ, wantR, wantY, wantSse, p_begin, p_end)
+               : launch_jacobian_t<kFisheye, float>(h, P0, P1, st, sel, wantJ, wantR, wantY, wantSse, p_begin, p_end);
+}
+
+int launch_view_setup_any(calib_handle_s* h, const double* P0, const double* P1, const LMState* st, int sel) {
+    return h->dtype == CALIB_DTYPE_F64 ? launch_view_setup<double>(h, P0, P1, st, sel)
+                                       : launch_view_setup<float>(h, P0, P1, st, sel);
 }
 
 template <typename T, int C>
-int launch_gram_t(calib_handle_s* h, const LMState* st, int sel) {
+int launch_gram_t(calib_handle_s* h, const LMState* st, int sel, int item0, int item1, int64_t origin) {
     using T2 = typename Pair<T>::type;
-    if (h->n_items == 0) return CALIB_OK;
-    const int blocks = (h->n_items + 3) / 4;
+    if (item1 <= item0) return CALIB_OK;
+    const int ipb = 4 / h->gram_wpi;       // items per workgroup
+    const int blocks = (item1 - item0 + ipb - 1) / ipb;
     int pi = prof_begin(h, 1);
     hipLaunchKernelGGL((gram_kernel<T, C>), dim3(blocks), dim3(256), 0, h->stream,
                        reinterpret_cast<const T2*>(h->J.p), reinterpret_cast<const T2*>(h->r.p),
-                       h->item_pt0.p, h->item_n.p, h->n_items, st, sel, h->G[0].p, h->G[1].p);
+                       h->item_pt0.p, h->item_n.p, item0, item1, origin, h->gram_wpi, st, sel, h->G[0].p,
+                       h->G[1].p);
     prof_end(h, pi);
     HIP_TRY(hipGetLastError());
     return CALIB_OK;
 }
 
-int launch_gram(calib_handle_s* h, const LMState* st, int sel) {
+int launch_gram(calib_handle_s* h, const LMState* st, int sel, int item0, int item1, int64_t origin) {
     if (h->dtype == CALIB_DTYPE_F64)
-        return h->model == CALIB_MODEL_RADTAN ? launch_gram_t<double, 16>(h, st, sel)
-                                              : launch_gram_t<double, 15>(h, st, sel);
-    return h->model == CALIB_MODEL_RADTAN ? launch_gram_t<float, 16>(h, st, sel)
-                                          : launch_gram_t<float, 15>(h, st, sel);
+        return h->model == CALIB_MODEL_RADTAN ? launch_gram_t<double, 16>(h, st, sel, item0, item1, origin)
+                                              : launch_gram_t<double, 15>(h, st, sel, item0, item1, origin);
+    return h->model == CALIB_MODEL_RADTAN ? launch_gram_t<float, 16>(h, st, sel, item0, item1, origin)
+                                          : launch_gram_t<float, 15>(h, st, sel, item0, item1, origin);
 }
 
 int launch_schur_reduce(calib_handle_s* h, const LMState* st, double* red) {
@@ -191,8 +203,8 @@ int launch_schur_reduce(calib_handle_s* h, const LMState* st, double* red) {
                                h->G[1].p, st, h->view_item0.p, h->nv, h->part.p);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->part.p,
-                       h->nv > 0 ? h->schur_blocks : 0, VA, h->sse_part.p, h->n_tiles, st, red);
+    hipLaunchKernelGGL(reduce_kernel, dim3(2 * VA), dim3(64), 0, h->stream, h->part.p,
+                       h->nv > 0 ? h->schur_blocks : 0, VA, st, red);
     HIP_TRY(hipGetLastError());
     return CALIB_OK;
 }
@@ -350,11 +362,48 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
     }
     h->nv = (int)view_ext.size();
     h->n_items = (int)item_pt0.size();
+    {   // waves per gram item from the mean points per item: a wave wants >= 2 trips of 16 points
+        const double avg = h->n_items ? (double)MN / h->n_items : 0.0;
+        h->gram_wpi = avg >= 128 ? 4 : (avg >= 64 ? 2 : 1);
+        if (const char* e = std::getenv("CALIB_GRAM_WPI")) {      // tuning knob
+            const int w = std::atoi(e);
+            if (w == 1 || w == 2 || w == 4) h->gram_wpi = w;
+        }
+    }
     h->n_tiles = (MN + kTile - 1) / kTile;
     int mv = 1;
     for (int64_t t = 0; t < h->n_tiles; ++t) {
         const int64_t a = t * kTile, b = std::min<int64_t>(MN, a + kTile) - 1;
         mv = std::max(mv, pt_view[(size_t)b] - pt_view[(size_t)a] + 1);
+    }
+    {   // chunks of whole views, ~chunk_points each; tiles of a chunk start at the chunk's first point
+        // Measured on MI355X (c3, 2 M points): chunks small enough for the 256 MiB Infinity Cache
+        // do NOT make the J round trip cheaper (0.33 ms/iter at one chunk, 0.45 at 262 k points,
+        // 1.1 at 65 k), so the chunk only bounds the J buffer: 64 M points = 17 GB at C = 16, fp64.
+        int64_t target = (int64_t)1 << 26;
+        if (const char* e = std::getenv("CALIB_CHUNK_POINTS")) target = std::max<int64_t>(1, std::atoll(e));
+        h->chunks.clear();
+        h->max_chunk_points = 0;
+        int v = 0;
+        while (v < h->nv) {
+            calib_handle_s::Chunk c;
+            c.p0 = item_pt0[(size_t)view_item0[(size_t)v]];
+            c.item0 = view_item0[(size_t)v];
+            int64_t p1 = c.p0;
+            while (v < h->nv && (p1 - c.p0 < target)) {
+                const int last = view_item0[(size_t)v + 1] - 1;
+                p1 = item_pt0[(size_t)last] + item_n[(size_t)last];
+                ++v;
+            }
+            c.p1 = p1;
+            c.item1 = view_item0[(size_t)v];
+            h->chunks.push_back(c);
+            h->max_chunk_points = std::max(h->max_chunk_points, c.p1 - c.p0);
+            for (int64_t a = c.p0; a < c.p1; a += kTile) {
+                const int64_t b = std::min<int64_t>(c.p1, a + kTile) - 1;
+                mv = std::max(mv, pt_view[(size_t)b] - pt_view[(size_t)a] + 1);
+            }
+        }
     }
     h->max_views_per_tile = mv;
     const int per = kSchurThreads / 16;
@@ -417,15 +466,18 @@ int calib_eval(calib_handle_t h, const double* P, double* out_y, double* out_r, 
     if (!P) return fail(CALIB_E_INVALID, "P is null");
     const size_t ts = tsize(h);
     const int64_t MN = h->MN;
-    if (out_Jc) HIP_TRY(h->J.alloc((size_t)MN * h->C * 2 * ts));
+    const size_t MN4 = (size_t)((MN + 3) / 4 * 4);     // J is stored in groups of 4 points
+    if (out_Jc) HIP_TRY(h->J.alloc(MN4 * h->C * 2 * ts));
     if (out_y) HIP_TRY(h->y.alloc((size_t)MN * 2 * ts));
     HIP_TRY(h->red_own.alloc((size_t)reduceSize(h->L)));
     HIP_TRY(hipMemcpyAsync(h->Peval.p, P, (size_t)numParams(h) * 8, hipMemcpyHostToDevice, h->stream));
-    rc = launch_jacobian(h, h->Peval.p, nullptr, h->st_eval.p, 0, out_Jc != nullptr, out_r != nullptr,
-                         out_y != nullptr);
+    rc = launch_view_setup_any(h, h->Peval.p, nullptr, h->st_eval.p, 0);
     if (rc) return rc;
-    hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(256), 0, h->stream, (const double*)nullptr, 0, 0,
-                       h->sse_part.p, h->n_tiles, h->st_eval.p, h->red_own.p);
+    rc = launch_jacobian(h, h->Peval.p, nullptr, h->st_eval.p, 0, out_Jc != nullptr, out_r != nullptr,
+                         out_y != nullptr, true, 0, MN);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sse_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->sse_part.p, h->n_tiles,
+                       h->red_own.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (out_sse) HIP_TRY(hipMemcpy(out_sse, h->red_own.p, 8, hipMemcpyDeviceToHost));
@@ -443,9 +495,9 @@ int calib_eval(calib_handle_t h, const double* P, double* out_y, double* out_r, 
     if (out_y && MN) { rc = fetch2(h->y.p, out_y); if (rc) return rc; }
     if (out_r && MN) { rc = fetch2(h->r.p, out_r); if (rc) return rc; }
     if (out_Jc && MN) {
-        // device layout [MN][C](du,dv) -> caller layout (MN,2,C)
+        // device layout jIndex(p, c)(du,dv) -> caller layout (MN,2,C)
         const int C = h->C;
-        const size_t cnt = (size_t)MN * C * 2;
+        const size_t cnt = MN4 * C * 2;
         std::vector<double> tmp(cnt);
         if (h->dtype == CALIB_DTYPE_F64) {
             HIP_TRY(hipMemcpy(tmp.data(), h->J.p, cnt * 8, hipMemcpyDeviceToHost));
@@ -456,8 +508,8 @@ int calib_eval(calib_handle_t h, const double* P, double* out_y, double* out_r, 
         }
         for (int64_t p = 0; p < MN; ++p)
             for (int c = 0; c < C; ++c) {
-                out_Jc[(p * 2 + 0) * C + c] = tmp[((size_t)p * C + c) * 2 + 0];
-                out_Jc[(p * 2 + 1) * C + c] = tmp[((size_t)p * C + c) * 2 + 1];
+                out_Jc[(p * 2 + 0) * C + c] = tmp[(size_t)jIndex(p, c, C) * 2 + 0];
+                out_Jc[(p * 2 + 1) * C + c] = tmp[(size_t)jIndex(p, c, C) * 2 + 1];
             }
     }
     return CALIB_OK;
@@ -490,7 +542,7 @@ int calib_lm_begin(calib_handle_t h, const double* P0, int max_iters, double lam
         return fail(CALIB_E_SINGULAR, "a view without points makes J^T J + lambda diag(J^T J) singular");
     const size_t ts = tsize(h);
     const int64_t K = numParams(h);
-    HIP_TRY(h->J.alloc((size_t)h->MN * h->C * 2 * ts));
+    HIP_TRY(h->J.alloc((size_t)((h->max_chunk_points + 3) / 4 * 4) * h->C * 2 * ts));
     HIP_TRY(h->G[0].alloc((size_t)std::max(h->n_items, 1) * kGStride));
     HIP_TRY(h->G[1].alloc((size_t)std::max(h->n_items, 1) * kGStride));
     HIP_TRY(h->part.alloc((size_t)2 * h->schur_blocks * variantSize(h->L)));
@@ -519,10 +571,14 @@ int calib_lm_begin(calib_handle_t h, const double* P0, int max_iters, double lam
 int calib_lm_local(calib_handle_t h) {
     CHECK_H(h);
     if (!h->lm_active) return fail(CALIB_E_STATE, "calib_lm_begin has not been called");
-    int rc = launch_jacobian(h, h->P[0].p, h->P[1].p, h->st.p, 1, true, true, false);
+    int rc = launch_view_setup_any(h, h->P[0].p, h->P[1].p, h->st.p, 1);
     if (rc) return rc;
-    rc = launch_gram(h, h->st.p, 1);
-    if (rc) return rc;
+    for (const auto& c : h->chunks) {
+        rc = launch_jacobian(h, h->P[0].p, h->P[1].p, h->st.p, 1, true, true, false, false, c.p0, c.p1);
+        if (rc) return rc;
+        rc = launch_gram(h, h->st.p, 1, c.item0, c.item1, c.p0);
+        if (rc) return rc;
+    }
     return launch_schur_reduce(h, h->st.p, h->red);
 }
 
@@ -635,8 +691,8 @@ int calib_normal_eq(calib_handle_t h, const double* P, double* out_B, double* ou
     const int L = h->L;
     std::vector<double> red((size_t)reduceSize(L));
     HIP_TRY(hipMemcpy(red.data(), h->red, red.size() * 8, hipMemcpyDeviceToHost));
-    if (out_B) std::memcpy(out_B, red.data() + 1, (size_t)L * L * 8);
-    if (out_g) std::memcpy(out_g, red.data() + 1 + 2 * L * L, (size_t)L * 8);
+    if (out_B) std::memcpy(out_B, red.data(), (size_t)L * L * 8);
+    if (out_g) std::memcpy(out_g, red.data() + 2 * L * L, (size_t)L * 8);
     if (out_E || out_V || out_g) {
         std::vector<double> G((size_t)h->n_items * kGStride);
         std::vector<int> vi0((size_t)h->nv + 1);

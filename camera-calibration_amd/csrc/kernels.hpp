@@ -16,12 +16,39 @@ namespace calib {
 
 constexpr int kTile = 256;        // points per jacobian workgroup
 constexpr int kGramChunk = 512;   // points per gram work item (one wave)
-constexpr int kGStride = 272;     // doubles per item: G 16x16 + g 16
+constexpr int kGramUnroll = 4;    // 4-point groups (1 KiB wave-loads of J) in flight per trip
+constexpr int kGStride = 288;     // doubles per item: G 16x16, g 16, [272] = sum r^2 (rest pad)
 constexpr int kMaxL = 10;
+
+// Compact Jacobian in HBM: groups of 4 points, [group][column][point-in-group] of (du, dv) pairs.
+// The jacobian kernel's store of one column then writes 64 B per 4 lanes (instead of 16 B per
+// lane at a C*16 B stride), and the 4 points x 16 columns a gram wave-load needs are still one
+// contiguous 1 KiB (any lane permutation inside it coalesces the same).
+__host__ __device__ __forceinline__ constexpr int64_t jIndex(int64_t p, int c, int C) {
+    return ((p >> 2) * C + c) * 4 + (p & 3);
+}
 constexpr int kSchurThreads = 128;  // 8 views (16 lanes each) per workgroup
-constexpr int kMaxSchurBlocks = 256;
+constexpr int kMaxSchurBlocks = 1024;
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+
+// every lane fetches `v` of lane `srcLane` (ds_bpermute: LDS crossbar, no LDS memory)
+__device__ __forceinline__ double2 lane_gather(double2 v, int srcLane) {
+    const int a = srcLane << 2;
+    int2 lo = __builtin_bit_cast(int2, v.x), hi = __builtin_bit_cast(int2, v.y);
+    lo.x = __builtin_amdgcn_ds_bpermute(a, lo.x);  lo.y = __builtin_amdgcn_ds_bpermute(a, lo.y);
+    hi.x = __builtin_amdgcn_ds_bpermute(a, hi.x);  hi.y = __builtin_amdgcn_ds_bpermute(a, hi.y);
+    double2 o;
+    o.x = __builtin_bit_cast(double, lo);  o.y = __builtin_bit_cast(double, hi);
+    return o;
+}
+__device__ __forceinline__ float2 lane_gather(float2 v, int srcLane) {
+    const int a = srcLane << 2;
+    float2 o;
+    o.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a, __builtin_bit_cast(int, v.x)));
+    o.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a, __builtin_bit_cast(int, v.y)));
+    return o;
+}
 
 struct LMState {
     double lam, err_cur, last_err, lam_min, lam_max, err_min;
@@ -36,11 +63,12 @@ struct LMState {
     double dc[kMaxL];
 };
 
-// reduce-buffer layout (doubles): [0] err_cand, then two variants of
-//   Bsum[L*L] Ssub[L*L] gc[L] ssub[L] nfail
-// variant A = candidate blocks with lambda_accept, B = current blocks with lambda_reject.
-__host__ __device__ constexpr int variantSize(int L) { return 2 * L * L + 2 * L + 1; }
-__host__ __device__ constexpr int reduceSize(int L) { return 1 + 2 * variantSize(L); }
+// reduce-buffer layout (doubles): two variants of
+//   Bsum[L*L] Ssub[L*L] gc[L] ssub[L] nfail sse
+// variant A = candidate blocks with lambda_accept (its sse is err(candidate)),
+// variant B = current blocks with lambda_reject.
+__host__ __device__ constexpr int variantSize(int L) { return 2 * L * L + 2 * L + 2; }
+__host__ __device__ constexpr int reduceSize(int L) { return 2 * variantSize(L); }
 
 __device__ __forceinline__ const double* selectP(const double* P0, const double* P1,
                                                  const LMState* st, int sel) {
@@ -83,9 +111,10 @@ template <typename T>
 struct JacArgs {
     using T2 = typename Pair<T>::type;
     const double* P0; const double* P1; const LMState* st; int sel;
-    const T2* uv; const T2* XY; const T* Z; const int* pt_view; int64_t MN;
+    const T2* uv; const T2* XY; const T* Z; const int* pt_view;
+    int64_t p_begin, p_end;   // this launch covers points [p_begin, p_end) (a chunk of whole views)
     const T* VC;
-    T2* J;        // [MN][C] (du, dv)     may be null (projection / error only)
+    T2* J;        // jIndex(p - p_begin, c, C) (du, dv)   may be null (projection / error only)
     T2* r;        // [MN]                 may be null
     T2* y;        // [MN] projection      may be null
     double* sse_part;   // [numTiles]
@@ -101,9 +130,9 @@ __global__ __launch_bounds__(kTile) void jacobian_kernel(JacArgs<T> a) {
     if (a.sel && a.st->done) return;
     const double* P = selectP(a.P0, a.P1, a.st, a.sel);
     const int tid = threadIdx.x;
-    const int64_t tile0 = (int64_t)blockIdx.x * kTile;
+    const int64_t tile0 = a.p_begin + (int64_t)blockIdx.x * kTile;
     const int64_t p = tile0 + tid;
-    const int64_t last = (tile0 + kTile < a.MN ? tile0 + kTile : a.MN) - 1;
+    const int64_t last = (tile0 + kTile < a.p_end ? tile0 + kTile : a.p_end) - 1;
     const int v0 = a.pt_view[tile0];
     const int nvt = a.pt_view[last] - v0 + 1;
     const T* src = a.VC + (int64_t)v0 * kViewStride;
@@ -111,7 +140,7 @@ __global__ __launch_bounds__(kTile) void jacobian_kernel(JacArgs<T> a) {
     __syncthreads();
 
     double e = 0.0;
-    if (p < a.MN) {
+    if (p < a.p_end) {
         Shared<MODEL, T> sp;
         sp.load(P);
         const T2 m = a.uv[p];
@@ -122,9 +151,9 @@ __global__ __launch_bounds__(kTile) void jacobian_kernel(JacArgs<T> a) {
         if (a.J) {
             T Ju[C], Jv[C];
             jacobian_point<MODEL, T>(sp, vc, xy.x, xy.y, z, u, v, Ju, Jv);
-            T2* dst = a.J + p * C;
+            T2* dst = a.J + jIndex(p - a.p_begin, 0, C);
 #pragma unroll
-            for (int c = 0; c < C; ++c) { T2 t; t.x = Ju[c]; t.y = Jv[c]; dst[c] = t; }
+            for (int c = 0; c < C; ++c) { T2 t; t.x = Ju[c]; t.y = Jv[c]; dst[4 * c] = t; }
         } else {
             project_point<MODEL, T>(sp, vc, xy.x, xy.y, z, u, v);
         }
@@ -133,6 +162,7 @@ __global__ __launch_bounds__(kTile) void jacobian_kernel(JacArgs<T> a) {
         if (a.y) { T2 t; t.x = u; t.y = v; a.y[p] = t; }
         e = (double)ru * (double)ru + (double)rv * (double)rv;
     }
+    if (!a.sse_part) return;      // LM rounds take sum r^2 from the gram kernel
     // fixed-order reduction: wave shuffle tree, then the 4 wave sums in order
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) e += __shfl_down(e, off, 64);
@@ -142,48 +172,100 @@ __global__ __launch_bounds__(kTile) void jacobian_kernel(JacArgs<T> a) {
 }
 
 // ---------------------------------------------------------------- gram (J^T J, J^T r)
-// One wave per item (<= kGramChunk points of one view). Lane l = (k = l>>4, c = l&15)
-// loads the 16-byte (du, dv) chunk of point 4g+k, column c: one wave-load is 1 KiB
-// contiguous and is at once the A and the B operand of v_mfma_f64_16x16x4_f64
-// (A[i][k] = J[row k][col i], B[k][j] = J[row k][col j]); u rows and v rows go through
-// two MFMAs. J^T r rides on the VALU with a 2-step cross-lane sum at the end.
+// One item = <= kGramChunk points of one view, worked on by WPI waves of a workgroup (1, 2 or 4,
+// chosen per problem from the points per item; the item's 4-point groups are split between them
+// and their partial tiles summed through LDS in wave order). Lane l = (k = l>>4, c = l&15)
+// loads the 16-byte (du, dv) chunk of point 4g+k, column c: one wave-load is 1 KiB contiguous
+// and is at once the A and the B operand of v_mfma_f64_16x16x4_f64 (A[i][k] = J[row k][col i],
+// B[k][j] = J[row k][col j]); u rows and v rows go through two MFMAs. J^T r and sum r^2 ride on
+// the VALU with a 2-step cross-lane sum at the end.
 template <typename T, int C>
 __global__ __launch_bounds__(256) void gram_kernel(const typename Pair<T>::type* __restrict__ J,
                                                    const typename Pair<T>::type* __restrict__ r,
                                                    const int64_t* __restrict__ item_pt0,
-                                                   const int* __restrict__ item_n, int n_items,
+                                                   const int* __restrict__ item_n, int item_begin,
+                                                   int item_end, int64_t j_origin, int wpi,
                                                    const LMState* __restrict__ st, int sel,
                                                    double* __restrict__ G0, double* __restrict__ G1) {
     using T2 = typename Pair<T>::type;
+    __shared__ double sred[4][kGStride];
     if (sel && st->done) return;
-    const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= n_items) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = wave % wpi;
+    const int item = item_begin + blockIdx.x * (4 / wpi) + wave / wpi;
+    const bool valid = item < item_end;
     const int c = lane & 15, k = lane >> 4;
-    const int64_t p0 = item_pt0[item];
-    const int n = item_n[item];
     const bool cvalid = c < C;
+    const int cc = cvalid ? c : C - 1;          // lane 15 of a 15-column model re-reads column 14, zeroed below
     d4 acc = {0.0, 0.0, 0.0, 0.0};
-    double gacc = 0.0;
-    const T2* Jp = J + (p0 + k) * C + c;
-    const T2* rp = r + p0 + k;
-#pragma unroll 4
-    for (int g = 0; g < n; g += 4) {
-        const bool pv = (g + k) < n;
-        double jx = 0.0, jy = 0.0, rx = 0.0, ry = 0.0;
-        if (pv) { const T2 t = rp[g]; rx = (double)t.x; ry = (double)t.y; }
-        if (pv && cvalid) { const T2 t = Jp[(int64_t)g * C]; jx = (double)t.x; jy = (double)t.y; }
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jx, jx, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc, 0, 0, 0);
-        gacc += jx * rx + jy * ry;
-    }
-    gacc += __shfl_xor(gacc, 16, 64);
-    gacc += __shfl_xor(gacc, 32, 64);
-    double* G = (sel ? ((st->cur ^ 1) ? G1 : G0) : G0) + (int64_t)item * kGStride;
-    // f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+    double gacc = 0.0, eacc = 0.0;
+    if (valid) {
+        // The item's points [pbeg, pend) are walked in the storage groups of jIndex (4 points,
+        // 4*C chunks of 16 B): lane l loads chunk l of the group -- adjacent lanes, adjacent
+        // addresses -- and one ds_bpermute per dword hands lane (k, c) its operand, chunk 4c+k.
+        // Points of a boundary group that belong to a neighbouring view are zeroed.
+        // q = p - j_origin indexes the chunk's J buffer; r is indexed by the absolute p
+        const int64_t pbeg = item_pt0[item] - j_origin, pend = pbeg + item_n[item];
+        const T2* rq = r + j_origin;
+        const int64_t grp0 = pbeg >> 2, grp1 = (pend + 3) >> 2;
+        const int per = (int)((grp1 - grp0 + wpi - 1) / wpi);
+        const int64_t gb = grp0 + (int64_t)sub * per;
+        const int64_t ge = gb + per < grp1 ? gb + per : grp1;
+        const int chunk = lane < 4 * C ? lane : 4 * C - 1;
+        const int srcLane = 4 * cc + k;
+        for (int64_t g = gb; g < ge; g += kGramUnroll) {
+            T2 raw[kGramUnroll], rv[kGramUnroll];
+            bool pv[kGramUnroll];
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) G[(k + 4 * reg) * 16 + c] = acc[reg];
-    if (k == 0) G[256 + c] = gacc;
+            for (int u = 0; u < kGramUnroll; ++u) {
+                const int64_t gu = g + u < ge ? g + u : ge - 1;
+                const int64_t pt = 4 * (g + u) + k;
+                pv[u] = (g + u < ge) && pt >= pbeg && pt < pend;
+                raw[u] = J[gu * (4 * C) + chunk];
+                rv[u] = rq[pv[u] ? pt : pbeg];
+            }
+#pragma unroll
+            for (int u = 0; u < kGramUnroll; ++u) {
+                const T2 jv = lane_gather(raw[u], srcLane);
+                const bool ok = pv[u];
+                const double rx = ok ? (double)rv[u].x : 0.0, ry = ok ? (double)rv[u].y : 0.0;
+                const double jx = (ok && cvalid) ? (double)jv.x : 0.0;
+                const double jy = (ok && cvalid) ? (double)jv.y : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jx, jx, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc, 0, 0, 0);
+                gacc += jx * rx + jy * ry;
+                eacc += rx * rx + ry * ry;
+            }
+        }
+        gacc += __shfl_xor(gacc, 16, 64);
+        gacc += __shfl_xor(gacc, 32, 64);
+        eacc += __shfl_xor(eacc, 16, 64);
+        eacc += __shfl_xor(eacc, 32, 64);
+    }
+    double* Gbase = sel ? ((st->cur ^ 1) ? G1 : G0) : G0;
+    // f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+    if (wpi == 1) {
+        if (!valid) return;
+        double* G = Gbase + (int64_t)item * kGStride;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) G[(k + 4 * reg) * 16 + c] = acc[reg];
+        if (k == 0) G[256 + c] = gacc;
+        if (lane == 0) G[272] = eacc;           // sum over the item's points of |r|^2
+        return;
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) sred[wave][(k + 4 * reg) * 16 + c] = acc[reg];
+    if (k == 0) sred[wave][256 + c] = gacc;
+    if (lane == 0) sred[wave][272] = eacc;
+    __syncthreads();
+    if (sub == 0 && valid) {                    // the item's first wave sums the partials in wave order
+        double* G = Gbase + (int64_t)item * kGStride;
+        for (int i = lane; i < 273; i += 64) {
+            double t = sred[wave][i];
+            for (int w = 1; w < wpi; ++w) t += sred[wave + w][i];
+            G[i] = t;
+        }
+    }
 }
 
 // ---------------------------------------------------------------- per-view elimination
@@ -200,15 +282,17 @@ struct Elim {
 };
 
 __device__ __forceinline__ void load_view_col(const double* __restrict__ G, int item0, int nitems,
-                                              int c, double (&col)[16], double& gc) {
+                                              int c, double (&col)[16], double& gc, double& sse) {
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) col[rr] = 0.0;
     gc = 0.0;
+    sse = 0.0;
     for (int it = 0; it < nitems; ++it) {
         const double* g = G + (int64_t)(item0 + it) * kGStride;
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) col[rr] += g[rr * 16 + c];
         gc += g[256 + c];
+        sse += g[272];
     }
 }
 
@@ -262,7 +346,7 @@ __global__ __launch_bounds__(kSchurThreads) void schur_kernel(const double* __re
                                                               const int* __restrict__ view_item0,
                                                               int nv, double* __restrict__ part) {
     constexpr int VA = variantSize(L);
-    constexpr int NACC = 2 * L + 3;
+    constexpr int NACC = 2 * L + 4;
     __shared__ double sacc[kSchurThreads / 16][16][NACC];
     if (st->done) return;
     const int variant = blockIdx.y;
@@ -278,16 +362,17 @@ __global__ __launch_bounds__(kSchurThreads) void schur_kernel(const double* __re
     const double* G = buf ? G1 : G0;
     const double lam = variant == 0 ? (boot ? st->lam : st->lam / 10) : st->lam * 10;
 
-    double Bacc[L], Sacc[L], gacc = 0.0, sac = 0.0, nfail = 0.0;
+    double Bacc[L], Sacc[L], gacc = 0.0, sac = 0.0, nfail = 0.0, eacc = 0.0;
 #pragma unroll
     for (int i = 0; i < L; ++i) { Bacc[i] = 0.0; Sacc[i] = 0.0; }
     const int groupsPerBlock = kSchurThreads / 16;
     for (int v = blockIdx.x * groupsPerBlock + grp; v < nv; v += gridDim.x * groupsPerBlock) {
-        double col[16], gc;
+        double col[16], gc, sse;
         const int i0 = view_item0[v];
-        load_view_col(G, i0, view_item0[v + 1] - i0, c, col, gc);
+        load_view_col(G, i0, view_item0[v + 1] - i0, c, col, gc, sse);
         Elim<L> e;
         eliminate<L>(col, gc, lam, e);
+        eacc += sse;
         double dzg = 0.0;
 #pragma unroll
         for (int m = 0; m < 6; ++m) dzg += e.z[m] * e.zg[m];
@@ -308,6 +393,7 @@ __global__ __launch_bounds__(kSchurThreads) void schur_kernel(const double* __re
     sacc[grp][c][2 * L] = gacc;
     sacc[grp][c][2 * L + 1] = sac;
     sacc[grp][c][2 * L + 2] = nfail;
+    sacc[grp][c][2 * L + 3] = eacc;
     __syncthreads();
     if (grp == 0 && c < L) {
         double t[NACC];
@@ -320,113 +406,137 @@ __global__ __launch_bounds__(kSchurThreads) void schur_kernel(const double* __re
         for (int i = 0; i < L; ++i) { out[c * L + i] = t[i]; out[L * L + c * L + i] = t[L + i]; }
         out[2 * L * L + c] = t[2 * L];
         out[2 * L * L + L + c] = t[2 * L + 1];
-        if (c == 0) out[2 * L * L + 2 * L] = t[2 * L + 2];
+        if (c == 0) { out[2 * L * L + 2 * L] = t[2 * L + 2]; out[2 * L * L + 2 * L + 1] = t[2 * L + 3]; }
     }
 }
 
 // ---------------------------------------------------------------- reduce
-__global__ __launch_bounds__(256) void reduce_kernel(const double* __restrict__ part, int nblocks, int VA,
-                                                     const double* __restrict__ sse_part, int64_t n_sse,
-                                                     const LMState* __restrict__ st,
-                                                     double* __restrict__ red) {
-    __shared__ double ssum[256];
+// One wave per reduce-buffer element: lanes stride over the schur block partials, then a
+// fixed-order shuffle tree. grid = 2 * VA.
+__global__ __launch_bounds__(64) void reduce_kernel(const double* __restrict__ part, int nblocks, int VA,
+                                                    const LMState* __restrict__ st,
+                                                    double* __restrict__ red) {
     if (st->done) return;
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const int variant = i / VA, idx = i - variant * VA;
+    const double* src = part + (int64_t)variant * nblocks * VA + idx;
+    double t = 0.0;
+    for (int b = lane; b < nblocks; b += 64) t += src[(int64_t)b * VA];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if (lane == 0) red[i] = t;
+}
+
+// sum of the jacobian kernel's per-tile partials (calib_eval only), one workgroup
+__global__ __launch_bounds__(256) void sse_reduce_kernel(const double* __restrict__ sse_part, int64_t n,
+                                                         double* __restrict__ out) {
+    __shared__ double ssum[256];
     const int tid = threadIdx.x;
     double e = 0.0;
-    for (int64_t i = tid; i < n_sse; i += 256) e += sse_part[i];
+    for (int64_t i = tid; i < n; i += 256) e += sse_part[i];
     ssum[tid] = e;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if (tid < s) ssum[tid] += ssum[tid + s];
         __syncthreads();
     }
-    if (tid == 0) red[0] = ssum[0];
-    for (int i = tid; i < 2 * VA; i += 256) {
-        const int variant = i / VA, idx = i - variant * VA;
-        double t = 0.0;
-        for (int b = 0; b < nblocks; ++b) t += part[((int64_t)variant * nblocks + b) * VA + idx];
-        red[1 + i] = t;
-    }
+    if (tid == 0) out[0] = ssum[0];
 }
 
-// ---------------------------------------------------------------- update (1 thread)
-// The control flow of src/calibrate.py:155-168 on the device.
+// ---------------------------------------------------------------- update (16 lanes)
+// The control flow of src/calibrate.py:155-168 on the device, then the L x L solve
+// (J^T J + lam diag)^-1 restricted to the shared block: S dc = s. Lane i owns row i of [S | s];
+// Gauss-Jordan with partial pivoting across lanes (np.linalg.inv in the reference is LU with
+// partial pivoting as well). Every lane takes the same scalar decisions; lanes 0..15 write.
 template <int L>
-__global__ void update_kernel(LMState* __restrict__ st, const double* __restrict__ red,
-                              double* __restrict__ P0, double* __restrict__ P1,
-                              double* __restrict__ trace) {
+__global__ __launch_bounds__(64) void update_kernel(LMState* __restrict__ st, const double* __restrict__ red,
+                                                    double* __restrict__ P0, double* __restrict__ P1,
+                                                    double* __restrict__ trace) {
     constexpr int VA = variantSize(L);
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    constexpr int kNfail = 2 * L * L + 2 * L, kSse = kNfail + 1;
     if (st->done) return;
+    const int lane = threadIdx.x, i = lane & 15;
+    const bool writer = lane < 16;
     double* Pb[2] = {P0, P1};
     int cur = st->cur;
     const int cand = cur ^ 1;
-    const double err_cand = red[0];
+    const int round = st->round;
+    const double err_cand = red[kSse];
     double lam = st->lam;
-    const double* sys;
-    if (st->round == 0) {
+    const double* sys = red;
+    bool done = false;
+    if (round == 0) {
         cur = cand;
-        st->cur = cur;
-        st->err_cur = err_cand;
-        st->last_err = err_cand;
-        sys = red + 1;
+        if (lane == 0) { st->cur = cur; st->err_cur = err_cand; st->last_err = err_cand; }
     } else {
-        const int it = st->round - 1;
+        const int it = round - 1;
         const double err_cur = st->err_cur;
         const bool acc = err_cand < err_cur;      // strict; NaN rejects (src/calibrate.py:161)
-        if (trace) {
+        if (trace && writer) {
             double* row = trace + (int64_t)it * (5 + L);
-            row[0] = it; row[1] = err_cur; row[2] = err_cand; row[3] = lam; row[4] = acc ? 1.0 : 0.0;
-            for (int i = 0; i < L; ++i) row[5 + i] = Pb[cur][i];
+            if (i < L) row[5 + i] = Pb[cur][i];
+            if (i == 0) { row[0] = it; row[1] = err_cur; row[2] = err_cand; row[3] = lam; row[4] = acc ? 1.0 : 0.0; }
         }
-        st->last_err = err_cur;                   // the reference returns the pre-update error (:155,171)
-        if (acc) {
-            cur = cand; st->cur = cur; st->err_cur = err_cand;
-            lam = lam / 10; sys = red + 1;
-        } else {
-            lam = lam * 10; sys = red + 1 + VA;
-        }
-        st->lam = lam;
-        st->iters = it + 1;
-        st->accepted_last = acc ? 1 : 0;
-        if (!(st->lam_min < lam && lam < st->lam_max) || err_cur < st->err_min ||
-            it + 1 >= st->max_iters) {
-            st->done = 1;
-            st->round += 1;
-            return;
+        if (acc) { cur = cand; lam = lam / 10; } else { lam = lam * 10; sys = red + VA; }
+        done = !(st->lam_min < lam && lam < st->lam_max) || err_cur < st->err_min || it + 1 >= st->max_iters;
+        if (lane == 0) {
+            st->last_err = err_cur;               // the reference returns the pre-update error (:155,171)
+            if (acc) { st->cur = cur; st->err_cur = err_cand; }
+            st->lam = lam;
+            st->iters = it + 1;
+            st->accepted_last = acc ? 1 : 0;
         }
     }
-    st->round += 1;
-    if (sys[2 * L * L + 2 * L] > 0.0) { st->error = -3; st->done = 1; return; }
-    // S = B + lam diag(B) - sum E Vh^-1 E^T ; s = g_c - sum E Vh^-1 g_v
-    double S[L][L + 1];
-    for (int i = 0; i < L; ++i) {
-        for (int j = 0; j < L; ++j) S[i][j] = sys[i * L + j] - sys[L * L + i * L + j];
-        S[i][i] += lam * sys[i * L + i];
-        S[i][L] = sys[2 * L * L + i] - sys[2 * L * L + L + i];
+    if (lane == 0) { st->round = round + 1; if (done) st->done = 1; }
+    if (done) return;
+    if (sys[kNfail] > 0.0) { if (lane == 0) { st->error = -3; st->done = 1; } return; }
+
+    // row i of S = B + lam diag(B) - sum E Vh^-1 E^T, rhs s = g_c - sum E Vh^-1 g_v
+    double row[L + 1];
+#pragma unroll
+    for (int j = 0; j <= L; ++j) row[j] = 0.0;
+    if (i < L) {
+#pragma unroll
+        for (int j = 0; j < L; ++j) row[j] = sys[i * L + j] - sys[L * L + i * L + j];
+        row[L] = sys[2 * L * L + i] - sys[2 * L * L + L + i];
+        const double bii = sys[i * L + i];
+#pragma unroll
+        for (int j = 0; j < L; ++j) if (j == i) row[j] += lam * bii;
     }
-    // Gaussian elimination with partial pivoting
+    bool used = false, singular = false;
+    int myCol = -1;
+#pragma unroll
     for (int col = 0; col < L; ++col) {
-        int piv = col;
-        double best = fabs(S[col][col]);
-        for (int i = col + 1; i < L; ++i) if (fabs(S[i][col]) > best) { best = fabs(S[i][col]); piv = i; }
-        if (!(best > 0.0)) { st->error = -3; st->done = 1; return; }
-        if (piv != col) for (int j = col; j <= L; ++j) { const double t = S[col][j]; S[col][j] = S[piv][j]; S[piv][j] = t; }
-        const double inv = 1.0 / S[col][col];
-        for (int i = col + 1; i < L; ++i) {
-            const double f = S[i][col] * inv;
-            for (int j = col; j <= L; ++j) S[i][j] -= f * S[col][j];
+        double best = (!used && i < L) ? fabs(row[col]) : -1.0;
+        int bi = i;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            const double ob = __shfl_xor(best, off, 16);
+            const int oi = __shfl_xor(bi, off, 16);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (!(best > 0.0)) singular = true;
+        double prow[L + 1];
+#pragma unroll
+        for (int j = col; j <= L; ++j) prow[j] = __shfl(row[j], bi, 16);
+        if (i == bi) {
+            used = true;
+            myCol = col;
+        } else {
+            const double f = row[col] / prow[col];
+#pragma unroll
+            for (int j = col + 1; j <= L; ++j) row[j] -= f * prow[j];
+            row[col] = 0.0;
         }
     }
-    double dc[L];
-    for (int i = L - 1; i >= 0; --i) {
-        double t = S[i][L];
-        for (int j = i + 1; j < L; ++j) t -= S[i][j] * dc[j];
-        dc[i] = t / S[i][i];
-    }
-    for (int i = 0; i < L; ++i) {
-        st->dc[i] = dc[i];
-        Pb[cur ^ 1][i] = Pb[cur][i] + dc[i];
+    if (singular) { if (lane == 0) { st->error = -3; st->done = 1; } return; }
+    double piv = 1.0;
+#pragma unroll
+    for (int j = 0; j < L; ++j) if (myCol == j) piv = row[j];
+    if (writer && myCol >= 0) {
+        const double d = row[L] / piv;
+        st->dc[myCol] = d;
+        Pb[cur ^ 1][myCol] = Pb[cur][myCol] + d;
     }
 }
 
@@ -448,9 +558,9 @@ __global__ __launch_bounds__(kSchurThreads) void backsub_kernel(const double* __
     const double* G = cur ? G1 : G0;
     const double* Pc = cur ? P1 : P0;
     double* Pn = cur ? P0 : P1;
-    double col[16], gc;
+    double col[16], gc, sse;
     const int i0 = view_item0[v];
-    load_view_col(G, i0, view_item0[v + 1] - i0, c, col, gc);
+    load_view_col(G, i0, view_item0[v + 1] - i0, c, col, gc, sse);
     Elim<L> e;
     eliminate<L>(col, gc, st->lam, e);
     const double dcc = c < L ? st->dc[c] : 0.0;
