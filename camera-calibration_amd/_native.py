@@ -28,7 +28,7 @@ SIGNATURES = {
     "calib_device_count": (ctypes.c_int, [_c_int_p]),
     "calib_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_h)]),
     "calib_destroy": (ctypes.c_int, [_h]),
-    "calib_set_stream": (ctypes.c_int, [_h, ctypes.c_void_p]),
+    "calib_set_stream": (ctypes.c_int, [_h, ctypes.c_void_p, ctypes.c_int]),
     "calib_set_problem": (ctypes.c_int, [_h, ctypes.c_int64, _c_int64_p, _c_double_p, _c_double_p]),
     "calib_num_shared": (ctypes.c_int, [_h, _c_int_p]),
     "calib_num_params": (ctypes.c_int, [_h, _c_int64_p]),

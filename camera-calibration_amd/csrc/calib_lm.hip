@@ -307,10 +307,10 @@ int calib_destroy(calib_handle_t h) {
     return CALIB_OK;
 }
 
-int calib_set_stream(calib_handle_t h, void* hip_stream) {
+int calib_set_stream(calib_handle_t h, void* hip_stream, int use_own) {
     CHECK_H(h);
     HIP_TRY(hipStreamSynchronize(h->stream));
-    h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+    h->stream = use_own ? h->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
     return CALIB_OK;
 }
 

@@ -106,7 +106,12 @@ class RefineEngine:
         self.viewOffsets = offs
 
     def setStream(self, hipStream):
-        nat.check(self._lib.calib_set_stream(self._h, ctypes.c_void_p(hipStream or 0)))
+        """Run on an existing HIP stream, given as an integer handle (0 = the default stream, which
+        is torch's current stream unless changed); None = back to the engine's own stream."""
+        if hipStream is None:
+            nat.check(self._lib.calib_set_stream(self._h, None, 1))
+        else:
+            nat.check(self._lib.calib_set_stream(self._h, ctypes.c_void_p(int(hipStream)), 0))
 
     def _P(self, P):
         P = np.ascontiguousarray(np.asarray(P, dtype=np.float64).ravel())

@@ -61,8 +61,10 @@ int calib_create(int model, int dtype, int device_id, calib_handle_t* out_handle
 int calib_destroy(calib_handle_t h);
 
 /* Launch all work of this handle on an existing HIP stream (e.g. the stream a
- * torch.distributed all-reduce is ordered against). NULL = the handle's own stream. */
-int calib_set_stream(calib_handle_t h, void* hip_stream);
+ * torch.distributed all-reduce is ordered against). use_own != 0: back to the handle's own
+ * (non-blocking) stream; otherwise hip_stream is used as given, NULL being the HIP default
+ * stream (which is what torch.cuda.current_stream().cuda_stream is unless the caller changed it). */
+int calib_set_stream(calib_handle_t h, void* hip_stream, int use_own);
 
 /* Upload the correspondences once (replaces getSensorPoints' vstack, src/calibrate.py:277-282).
  * sensor_uv: (MN,2) row-major as numpy, may be NULL (projection-only use);

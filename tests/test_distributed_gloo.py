@@ -1,0 +1,106 @@
+"""N > 1 path on CPU: the sharded-LM driver (camera-calibration_amd/distributed.py) over
+torch.distributed/gloo with world_size 2 and 3, using the oracle-backed shard stand-in.
+Checks that sharding + ONE sum all-reduce per LM round reproduces the unsharded result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from camera_calibration_amd import distributed
+from conftest import loadGolden
+from oracle import calib_oracle as orc
+from shard_double import OracleShardEngine
+
+
+def test_partition_views_balanced_and_contiguous():
+    g = loadGolden("g3_unittest15.npz")
+    offs = g["viewOffsets"]
+    for world in (1, 2, 3, 4, 8, 15, 20):
+        parts = distributed.partitionViews(offs, world)
+        assert len(parts) == world and parts[0][0] == 0 and parts[-1][1] == 15
+        for (a0, a1), (b0, b1) in zip(parts[:-1], parts[1:]):
+            assert a1 == b0 and a0 <= a1
+        pts = [int(offs[b] - offs[a]) for a, b in parts]
+        assert sum(pts) == int(offs[-1])
+        if world <= 4:
+            assert max(pts) - min(pts) <= 2 * int(np.diff(offs).max())
+    # uniform views split evenly
+    offs = np.arange(0, 54 * 1001, 54)
+    assert [b - a for a, b in distributed.partitionViews(offs, 8)] == [125] * 8
+
+
+def test_shard_problem_slices():
+    g = loadGolden("g3_unittest15.npz")
+    offs, s, m, P0 = g["viewOffsets"], g["sensorPoints"], g["modelPoints"], g["P0"]
+    Pl, ol, sl, ml = distributed.shardProblem(P0, offs, s, m, 10, (4, 9))
+    assert Pl.shape[0] == 10 + 6 * 5 and ol[0] == 0 and ol[-1] == sl.shape[0] == ml.shape[0]
+    assert np.array_equal(Pl[10:], P0[10 + 24:10 + 54]) and np.array_equal(sl, s[offs[4]:offs[9]])
+
+
+def _freePort():
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def _worker(rank, world, port, tag, modelId, maxIters, outDir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = loadGolden(tag)
+        offs, s, m, P0 = g["viewOffsets"], g["sensorPoints"], g["modelPoints"], g["P0"]
+        L = orc.numShared(modelId)
+        part = distributed.partitionViews(offs, world)[rank]
+        Pl, ol, sl, ml = distributed.shardProblem(P0, offs, s, m, L, part)
+        eng = OracleShardEngine(modelId, ol, sl, ml)
+        buf = torch.from_numpy(eng.red)           # shares memory with the engine's reduce buffer
+        calls = [0]
+
+        def allReduce():
+            calls[0] += 1
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+
+        lm = distributed.ShardedLM(eng, allReduce)
+        lm.begin(Pl, maxIters)
+        lm.run(maxIters, checkEvery=4)
+        sse, P, iters, trace = lm.end()
+        np.savez(os.path.join(outDir, f"rank{rank}.npz"), sse=sse, P=P, iters=iters, trace=trace,
+                 part=np.array(part), calls=calls[0])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,tag,modelId", [(2, "g3_unittest15.npz", orc.RADTAN),
+                                               (3, "g2_config1_fisheye.npz", orc.FISHEYE)])
+def test_sharded_lm_matches_unsharded(tmp_path, world, tag, modelId):
+    maxIters = 40
+    port = _freePort()
+    mp.spawn(_worker, args=(world, port, tag, modelId, maxIters, str(tmp_path)), nprocs=world, join=True)
+    g = loadGolden(tag)
+    offs, s, m, P0 = g["viewOffsets"], g["sensorPoints"], g["modelPoints"], g["P0"]
+    L = orc.numShared(modelId)
+    sseRef, Pref, traceRef = orc.refineSchur(modelId, P0, offs, s, m, maxIters)
+    outs = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+    P = np.empty_like(Pref)
+    for o in outs:
+        v0, v1 = o["part"]
+        assert int(o["iters"]) == int(outs[0]["iters"])                 # replicated control flow
+        assert np.array_equal(o["P"][:L], outs[0]["P"][:L])             # bitwise identical shared parameters
+        assert np.array_equal(o["trace"], outs[0]["trace"])
+        P[:L] = o["P"][:L]
+        P[L + 6 * v0:L + 6 * v1] = o["P"][L:]
+        # one all-reduce per LM round (bootstrap + executed iterations, up to the early-stop check)
+        assert int(o["calls"]) <= maxIters + 1
+    iters = int(outs[0]["iters"])
+    assert abs(iters - traceRef.shape[0]) <= 2
+    assert float(outs[0]["sse"]) < 1e-7 and sseRef < 1e-7
+    assert np.abs(P[:L] - Pref[:L]).max() < 1e-9
+    assert np.abs(P - Pref).max() < 1e-6
+    assert np.abs(P[:L] - g["Pfinal"][:L]).max() < 1e-9                 # the reference's own answer
+    n = min(5, iters)
+    assert np.array_equal(outs[0]["trace"][:n, 3], traceRef[:n, 3])

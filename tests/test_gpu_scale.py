@@ -1,0 +1,197 @@
+"""GPU tests at BASELINE.json sizes through size-independent properties, the fp32 path, and the
+multi-shard protocol driven on the real HIP engine (two shards on one GPU in lockstep; the
+torch.distributed/RCCL binding with world_size 1)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import camera_calibration_amd as cca
+from camera_calibration_amd import distributed, synthetic
+from oracle import calib_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def relIntr(P, Ptrue, L):
+    """max relative error of the shared parameters: alpha, beta, uc, vc relative to themselves, the
+    skew gamma (true value 0) relative to the focal length it scales with, distortion coefficients
+    relative to max(|k|, 1)."""
+    scale = np.maximum(np.abs(Ptrue[:L]), 1.0)
+    scale[2] = abs(Ptrue[0])
+    return float(np.max(np.abs(P[:L] - Ptrue[:L]) / scale))
+
+
+@pytest.fixture(scope="module")
+def c3():
+    # configs[2]: 10 000 views x 200 pts, fisheye, fp64 -- noise-free for exact-recovery properties
+    return synthetic.makeShard("c3", noiseSigma=0.0)
+
+
+def test_c3_full_size_properties(c3):
+    L = 9
+    offs, s, m, Ptrue, P0 = c3["viewOffsets"], c3["sensorPoints"], c3["modelPoints"], c3["Ptrue"], c3["P0"]
+    MN = int(offs[-1])
+    assert MN == 2_000_000
+    eng = cca.RefineEngine("fisheye", "f64")
+    eng.setProblem(offs, s, m)
+    # (1) zero error at the truth (tests/test_calibrate.py:123-133 at scale)
+    assert eng.evaluate(Ptrue)["sse"] < 1e-18 * MN
+    # (2) first-order consistency of projection and Jacobian along a random direction
+    rng = np.random.default_rng(1)
+    d = rng.standard_normal(P0.shape[0]) * np.maximum(np.abs(P0), 1e-2) * 1e-3
+    ev0 = eng.evaluate(P0, wantY=True, wantJ=True)
+    eps = 1e-4
+    yp = eng.evaluate(P0 + eps * d, wantY=True)["y"]
+    ym = eng.evaluate(P0 - eps * d, wantY=True)["y"]
+    vi = orc.pointViewIndex(offs)
+    dloc = np.concatenate((np.tile(d[:L], (MN, 1)), d[L:].reshape(-1, 6)[vi]), axis=1)      # (MN, C)
+    Jd = np.einsum("nrc,nc->nr", ev0["Jc"], dloc)
+    fd = (yp - ym) / (2 * eps)
+    assert np.abs(fd - Jd).max() <= 1e-5 * np.abs(Jd).max()
+    # (3) normal equations are the Gram of the compact Jacobian: checksum of all view blocks
+    B, E, V, g = eng.normalEquations(P0)
+    Js, Je = ev0["Jc"][:, :, :L], ev0["Jc"][:, :, L:]
+    r = s - ev0["y"]
+    Bn = np.einsum("nra,nrb->ab", Js, Js)
+    assert np.abs(B - Bn).max() <= 1e-10 * np.abs(Bn).max()
+    Vsum = np.einsum("nra,nrb->ab", Je, Je)
+    assert np.abs(V.sum(axis=0) - Vsum).max() <= 1e-10 * np.abs(Vsum).max()
+    Esum = np.einsum("nra,nrb->ab", Js, Je)
+    assert np.abs(E.sum(axis=0) - Esum).max() <= 1e-10 * np.abs(Esum).max()
+    gn = np.einsum("nra,nr->a", Js, r)
+    assert np.abs(g[:L] - gn).max() <= 1e-10 * np.abs(gn).max()
+    sample = [0, 1234, 9999]
+    for i in sample:
+        a, b = offs[i], offs[i + 1]
+        Vi = np.einsum("nra,nrb->ab", Je[a:b], Je[a:b])
+        assert np.abs(V[i] - Vi).max() <= 1e-11 * np.abs(Vi).max()
+    # (4) the LM loop recovers the truth from the perturbed start (noise-free)
+    sse, P, iters, trace = eng.refine(P0, 60)
+    assert sse < 1e-9 * MN and relIntr(P, Ptrue, L) < 1e-9
+    assert np.abs(P - Ptrue).max() < 1e-6
+    # (5) idempotence: refining the refined parameters does not move them
+    sse2, P2, iters2, _ = eng.refine(P, 3)
+    assert np.abs(P2 - P).max() < 1e-9
+    eng.close()
+
+
+def test_two_shards_in_lockstep_match_one_shard(c3):
+    """The multi-GPU protocol on the real engine: two handles each own half of the views; per LM
+    round their reduce buffers are summed (here on one GPU; across GPUs this sum is the RCCL
+    all-reduce) and each shard updates. Must agree with the unsharded run."""
+    import torch
+    L = 9
+    nv = 600
+    offs = c3["viewOffsets"][:nv + 1]
+    n = int(offs[-1])
+    s, m = c3["sensorPoints"][:n] + np.random.default_rng(2).normal(0, 0.1, (n, 2)), c3["modelPoints"][:n]
+    P0 = np.concatenate((c3["P0"][:L], c3["P0"][L:L + 6 * nv]))
+    ref = cca.RefineEngine("fisheye", "f64")
+    ref.setProblem(offs, s, m)
+    sseR, PR, itR, trR = ref.refine(P0, 25)
+    ref.close()
+    parts = distributed.partitionViews(offs, 2)
+    engs, bufs, locals_ = [], [], []
+    stream = torch.cuda.current_stream().cuda_stream
+    for part in parts:
+        Pl, ol, sl, ml = distributed.shardProblem(P0, offs, s, m, L, part)
+        e = cca.RefineEngine("fisheye", "f64")
+        e.setProblem(ol, sl, ml)
+        b = torch.zeros(e.reduceSize(), dtype=torch.float64, device="cuda")
+        e.setStream(stream)
+        e.bindReduceBuffer(b.data_ptr())
+        e.lmBegin(Pl, 25)
+        engs.append(e); bufs.append(b); locals_.append(Pl)
+    for rnd in range(26):
+        for e in engs:
+            e.lmLocal()
+        total = bufs[0] + bufs[1]
+        bufs[0].copy_(total); bufs[1].copy_(total)
+        for e in engs:
+            e.lmUpdate()
+    outs = [e.lmEnd() for e in engs]
+    # replicated control flow: both shards took the same decisions and hold identical shared params
+    assert outs[0][2] == outs[1][2] and np.array_equal(outs[0][3], outs[1][3])
+    assert np.array_equal(outs[0][1][:L], outs[1][1][:L])
+    # vs the unsharded run: at the noise floor accept/reject is decided by the rounding of the
+    # (differently ordered) sums, so compare the well-separated early trace and the converged result
+    assert abs(outs[0][2] - itR) <= 3
+    n = 6
+    assert np.array_equal(outs[0][3][:n, 3], trR[:n, 3]) and np.allclose(outs[0][3][:n, 1:3], trR[:n, 1:3], rtol=1e-10)
+    P = np.concatenate((outs[0][1][:L], outs[0][1][L:], outs[1][1][L:]))
+    assert np.abs(P - PR).max() <= 1e-7 * max(1.0, np.abs(PR).max())
+    assert abs(outs[0][0] - sseR) <= 1e-9 * sseR
+    for e in engs:
+        e.close()
+
+
+def test_torch_distributed_binding_world_size_1(c3):
+    """ShardedLM + torchAllReduce over the nccl (= RCCL) backend with one rank: the engine's kernels
+    run on torch's stream and the reduce buffer is a torch tensor."""
+    import torch
+    import torch.distributed as dist
+    L = 9
+    nv = 300
+    offs = c3["viewOffsets"][:nv + 1]
+    n = int(offs[-1])
+    s, m = c3["sensorPoints"][:n], c3["modelPoints"][:n]
+    P0 = np.concatenate((c3["P0"][:L], c3["P0"][L:L + 6 * nv]))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        eng = cca.RefineEngine("fisheye", "f64")
+        eng.setProblem(offs, s, m)
+        lm = distributed.ShardedLM(eng, distributed.torchAllReduce(eng, torch.device("cuda", 0)))
+        lm.begin(P0, 40)
+        lm.run(40, checkEvery=8)
+        sse, P, iters, trace = lm.end()
+        assert sse < 1e-9 * n and relIntr(P, c3["Ptrue"], L) < 1e-9 and iters < 40
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fp32_storage_path():
+    """configs[3] shape at reduced view count: radtan, fp32 points / J / r, fp64 normal equations."""
+    cfg = dict(synthetic.CONFIGS["c4"])
+    sh = synthetic.makeShard(cfg, numViews=2000, noiseSigma=0.0)
+    offs, s, m, Ptrue, P0 = sh["viewOffsets"], sh["sensorPoints"], sh["modelPoints"], sh["Ptrue"], sh["P0"]
+    L = 10
+    eng = cca.RefineEngine("radtan", "f32")
+    eng.setProblem(offs, s, m)
+    ev = eng.evaluate(P0, wantY=True, wantJ=True)
+    yo = orc.projectAllPoints(orc.RADTAN, P0, offs, m)
+    Jo = orc.jacobianCompact(orc.RADTAN, P0, offs, m)
+    assert np.abs(ev["y"] - yo).max() < 2e-3                     # fp32 pixels ~ 6e-5 ulp at 640 px
+    scale = np.abs(Jo).reshape(-1, 16).max(axis=0)
+    assert (np.abs(ev["Jc"] - Jo).reshape(-1, 16).max(axis=0) / scale).max() < 1e-4
+    sse, P, iters, trace = eng.refine(P0, 60)
+    # BASELINE.json bar: converged intrinsics within 1e-6 relative of the fp64 result
+    sse64, P64, tr64 = orc.refineSchur(orc.RADTAN, P0, offs, s, m, 60)
+    assert relIntr(P, P64, L) < 1e-6, relIntr(P, P64, L)
+    assert relIntr(P, Ptrue, L) < 1e-6
+    eng.close()
+
+
+def test_c5_shape_single_shard_sample():
+    """configs[4] shard shape (11x8 board, 88 pts/view): 20 000 views, noisy, vs the oracle's
+    Schur-form loop on the same inputs (the dense reference form is infeasible at this size)."""
+    sh = synthetic.makeShard("c5", numViews=20000, noiseSigma=0.1)
+    offs, s, m, P0 = sh["viewOffsets"], sh["sensorPoints"], sh["modelPoints"], sh["P0"]
+    eng = cca.RefineEngine("radtan", "f64")
+    eng.setProblem(offs, s, m)
+    d = eng.stepDelta(P0, 1e-3)
+    do = orc.lmStepSchur(orc.RADTAN, P0, offs, s, m, 1e-3)
+    assert np.linalg.norm(d - do) / np.linalg.norm(do) < 1e-8
+    sse, P, iters, trace = eng.refine(P0, 12)
+    sseO, PO, trO = orc.refineSchur(orc.RADTAN, P0, offs, s, m, 12)
+    assert abs(sse - sseO) <= 1e-9 * sseO
+    assert relIntr(P, PO, 10) < 1e-8
+    n = min(6, iters)
+    assert np.array_equal(trace[:n, 3], trO[:n, 3]) and np.allclose(trace[:n, 1], trO[:n, 1], rtol=1e-9)
+    eng.close()
