@@ -15,6 +15,7 @@ MODEL_RADTAN, MODEL_FISHEYE = 0, 1
 DTYPE_F64, DTYPE_F32 = 0, 1
 E_INVALID, E_HIP, E_SINGULAR, E_STATE = -1, -2, -3, -4
 TRACE_HEADER = 5
+LM_FUSED, LM_TWO_KERNEL = 0, 1
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)
 _c_int64_p = ctypes.POINTER(ctypes.c_int64)
@@ -30,6 +31,7 @@ SIGNATURES = {
     "calib_destroy": (ctypes.c_int, [_h]),
     "calib_set_stream": (ctypes.c_int, [_h, ctypes.c_void_p, ctypes.c_int]),
     "calib_set_problem": (ctypes.c_int, [_h, ctypes.c_int64, _c_int64_p, _c_double_p, _c_double_p]),
+    "calib_set_lm_mode": (ctypes.c_int, [_h, ctypes.c_int]),
     "calib_num_shared": (ctypes.c_int, [_h, _c_int_p]),
     "calib_num_params": (ctypes.c_int, [_h, _c_int64_p]),
     "calib_eval": (ctypes.c_int, [_h, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),

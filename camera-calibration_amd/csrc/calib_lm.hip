@@ -72,14 +72,16 @@ struct calib_handle_s {
     int64_t n_tiles = 0;
     int max_views_per_tile = 1;
     int schur_blocks = 1;
-    int gram_wpi = 1;             // waves per gram item
+    int gram_wpi = 1;             // waves per gram item (two-kernel mode)
+    int fused_wpi = 1;            // waves per item of the fused kernel
     // LM rounds walk the points in chunks of whole views so that a chunk's compact J
     // (written by the jacobian kernel, read once by the gram kernel) can stay on-die
     struct Chunk { int64_t p0, p1; int item0, item1; };
     std::vector<Chunk> chunks;
     int64_t max_chunk_points = 0;
     DevBuf<unsigned char> uv, XY, Z, VC, J, r, y;   // typed by dtype
-    DevBuf<int> pt_view, view_ext, item_n, view_item0;
+    DevBuf<int> pt_view, view_ext, item_n, view_item0, item_view;
+    int lm_mode = CALIB_LM_FUSED;
     DevBuf<int64_t> item_pt0;
     DevBuf<double> sse_part, G[2], part, red_own, P[2], Peval, trace;
     DevBuf<LMState> st, st_eval;
@@ -141,6 +143,10 @@ int launch_jacobian_t(calib_handle_s* h, const double* P0, const double* P1, con
     a.r = wantR ? reinterpret_cast<T2*>(h->r.p) : nullptr;
     a.y = wantY ? reinterpret_cast<T2*>(h->y.p) : nullptr;
     a.sse_part = wantSse ? h->sse_part.p : nullptr;
+    a.nostore = std::getenv("CALIB_JAC_NOSTORE") ? 1 : 0;
+    if (a.nostore && sel) {     // timing experiment only: keep evaluating P[0] whatever the LM state says
+        a.sel = 0; a.st = h->st_eval.p;
+    }
     const size_t lds = 32 + (size_t)h->max_views_per_tile * kViewStride * sizeof(T);
     int pi = prof_begin(h, 0);
     const unsigned tiles = (unsigned)((p_end - p_begin + kTile - 1) / kTile);
@@ -189,6 +195,31 @@ int launch_gram(calib_handle_s* h, const LMState* st, int sel, int item0, int it
                                               : launch_gram_t<double, 15>(h, st, sel, item0, item1, origin);
     return h->model == CALIB_MODEL_RADTAN ? launch_gram_t<float, 16>(h, st, sel, item0, item1, origin)
                                           : launch_gram_t<float, 15>(h, st, sel, item0, item1, origin);
+}
+
+template <int MODEL, typename T>
+int launch_fused_t(calib_handle_s* h, const LMState* st, int sel) {
+    using T2 = typename Pair<T>::type;
+    if (h->n_items == 0) return CALIB_OK;
+    const int ipb = 4 / h->fused_wpi;
+    const int blocks = (h->n_items + ipb - 1) / ipb;
+    int pi = prof_begin(h, 2);
+    hipLaunchKernelGGL((fused_kernel<MODEL, T>), dim3(blocks), dim3(256), 0, h->stream, h->P[0].p, h->P[1].p,
+                       reinterpret_cast<const T2*>(h->uv.p), reinterpret_cast<const T2*>(h->XY.p),
+                       reinterpret_cast<const T*>(h->Z.p), reinterpret_cast<const T*>(h->VC.p),
+                       h->item_pt0.p, h->item_n.p, h->item_view.p, h->n_items, h->fused_wpi, st, sel,
+                       h->G[0].p, h->G[1].p);
+    prof_end(h, pi);
+    HIP_TRY(hipGetLastError());
+    return CALIB_OK;
+}
+
+int launch_fused(calib_handle_s* h, const LMState* st, int sel) {
+    if (h->dtype == CALIB_DTYPE_F64)
+        return h->model == CALIB_MODEL_RADTAN ? launch_fused_t<kRadtan, double>(h, st, sel)
+                                              : launch_fused_t<kFisheye, double>(h, st, sel);
+    return h->model == CALIB_MODEL_RADTAN ? launch_fused_t<kRadtan, float>(h, st, sel)
+                                          : launch_fused_t<kFisheye, float>(h, st, sel);
 }
 
 int launch_schur_reduce(calib_handle_s* h, const LMState* st, double* red) {
@@ -287,6 +318,7 @@ int calib_create(int model, int dtype, int device_id, calib_handle_t* out_handle
         return fail(CALIB_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
     h->stream = h->own_stream;
+    if (const char* e = std::getenv("CALIB_LM_MODE")) h->lm_mode = std::atoi(e) ? CALIB_LM_TWO_KERNEL : CALIB_LM_FUSED;
     *out_handle = h;
     return CALIB_OK;
 }
@@ -298,7 +330,7 @@ int calib_destroy(calib_handle_t h) {
     for (auto& e : h->ev) (void)hipEventDestroy(e);
     h->uv.release(); h->XY.release(); h->Z.release(); h->VC.release(); h->J.release();
     h->r.release(); h->y.release(); h->pt_view.release(); h->view_ext.release();
-    h->item_n.release(); h->view_item0.release(); h->item_pt0.release(); h->sse_part.release();
+    h->item_n.release(); h->view_item0.release(); h->item_view.release(); h->item_pt0.release(); h->sse_part.release();
     h->G[0].release(); h->G[1].release(); h->part.release(); h->red_own.release();
     h->P[0].release(); h->P[1].release(); h->Peval.release(); h->trace.release();
     h->st.release(); h->st_eval.release();
@@ -311,6 +343,14 @@ int calib_set_stream(calib_handle_t h, void* hip_stream, int use_own) {
     CHECK_H(h);
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->stream = use_own ? h->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
+    return CALIB_OK;
+}
+
+int calib_set_lm_mode(calib_handle_t h, int mode) {
+    CHECK_H(h);
+    if (mode != CALIB_LM_FUSED && mode != CALIB_LM_TWO_KERNEL) return fail(CALIB_E_INVALID, "unknown LM mode");
+    if (h->lm_active) return fail(CALIB_E_STATE, "cannot change the LM mode inside a run");
+    h->lm_mode = mode;
     return CALIB_OK;
 }
 
@@ -345,7 +385,7 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
     h->MN = MN;
 
     // host-side packing: SoA + compact (non-empty) view list + gram work items
-    std::vector<int> pt_view((size_t)MN), view_ext, item_n, view_item0;
+    std::vector<int> pt_view((size_t)MN), view_ext, item_n, view_item0, item_view;
     std::vector<int64_t> item_pt0;
     view_item0.push_back(0);
     for (int64_t i = 0; i < num_views; ++i) {
@@ -357,6 +397,7 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
         for (int64_t p = a; p < b; p += kGramChunk) {
             item_pt0.push_back(p);
             item_n.push_back((int)std::min<int64_t>(kGramChunk, b - p));
+            item_view.push_back(cv);
         }
         view_item0.push_back((int)item_pt0.size());
     }
@@ -365,9 +406,12 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
     {   // waves per gram item from the mean points per item: a wave wants >= 2 trips of 16 points
         const double avg = h->n_items ? (double)MN / h->n_items : 0.0;
         h->gram_wpi = avg >= 128 ? 4 : (avg >= 64 ? 2 : 1);
+        // fused kernel: one wave per item is fastest (measured c3: 84 us vs 102 us at 4) as long as
+        // there are enough items to fill the chip; few big items are split over more waves
+        h->fused_wpi = h->n_items >= 2048 ? 1 : h->gram_wpi;
         if (const char* e = std::getenv("CALIB_GRAM_WPI")) {      // tuning knob
             const int w = std::atoi(e);
-            if (w == 1 || w == 2 || w == 4) h->gram_wpi = w;
+            if (w == 1 || w == 2 || w == 4) h->gram_wpi = h->fused_wpi = w;
         }
     }
     h->n_tiles = (MN + kTile - 1) / kTile;
@@ -416,6 +460,7 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
     HIP_TRY(h->pt_view.alloc((size_t)MN));
     HIP_TRY(h->view_ext.alloc((size_t)h->nv));
     HIP_TRY(h->item_n.alloc((size_t)h->n_items));
+    HIP_TRY(h->item_view.alloc((size_t)h->n_items));
     HIP_TRY(h->item_pt0.alloc((size_t)h->n_items));
     HIP_TRY(h->view_item0.alloc((size_t)h->nv + 1));
     HIP_TRY(h->VC.alloc((size_t)std::max(h->nv, 1) * kViewStride * ts));
@@ -452,6 +497,7 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
     HIP_TRY(upload(h->pt_view.p, pt_view.data(), pt_view.size() * 4));
     HIP_TRY(upload(h->view_ext.p, view_ext.data(), view_ext.size() * 4));
     HIP_TRY(upload(h->item_n.p, item_n.data(), item_n.size() * 4));
+    HIP_TRY(upload(h->item_view.p, item_view.data(), item_view.size() * 4));
     HIP_TRY(upload(h->item_pt0.p, item_pt0.data(), item_pt0.size() * 8));
     HIP_TRY(upload(h->view_item0.p, view_item0.data(), view_item0.size() * 4));
     h->has_problem = true;
@@ -542,7 +588,8 @@ int calib_lm_begin(calib_handle_t h, const double* P0, int max_iters, double lam
         return fail(CALIB_E_SINGULAR, "a view without points makes J^T J + lambda diag(J^T J) singular");
     const size_t ts = tsize(h);
     const int64_t K = numParams(h);
-    HIP_TRY(h->J.alloc((size_t)((h->max_chunk_points + 3) / 4 * 4) * h->C * 2 * ts));
+    if (h->lm_mode == CALIB_LM_TWO_KERNEL)
+        HIP_TRY(h->J.alloc((size_t)((h->max_chunk_points + 3) / 4 * 4) * h->C * 2 * ts));
     HIP_TRY(h->G[0].alloc((size_t)std::max(h->n_items, 1) * kGStride));
     HIP_TRY(h->G[1].alloc((size_t)std::max(h->n_items, 1) * kGStride));
     HIP_TRY(h->part.alloc((size_t)2 * h->schur_blocks * variantSize(h->L)));
@@ -573,6 +620,11 @@ int calib_lm_local(calib_handle_t h) {
     if (!h->lm_active) return fail(CALIB_E_STATE, "calib_lm_begin has not been called");
     int rc = launch_view_setup_any(h, h->P[0].p, h->P[1].p, h->st.p, 1);
     if (rc) return rc;
+    if (h->lm_mode == CALIB_LM_FUSED) {
+        rc = launch_fused(h, h->st.p, 1);
+        if (rc) return rc;
+        return launch_schur_reduce(h, h->st.p, h->red);
+    }
     for (const auto& c : h->chunks) {
         rc = launch_jacobian(h, h->P[0].p, h->P[1].p, h->st.p, 1, true, true, false, false, c.p0, c.p1);
         if (rc) return rc;

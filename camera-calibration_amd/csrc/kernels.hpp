@@ -118,6 +118,7 @@ struct JacArgs {
     T2* r;        // [MN]                 may be null
     T2* y;        // [MN] projection      may be null
     double* sse_part;   // [numTiles]
+    int nostore;        // experiment: compute the block but skip its stores unless a value is NaN
 };
 
 template <int MODEL, typename T>
@@ -152,8 +153,17 @@ __global__ __launch_bounds__(kTile) void jacobian_kernel(JacArgs<T> a) {
             T Ju[C], Jv[C];
             jacobian_point<MODEL, T>(sp, vc, xy.x, xy.y, z, u, v, Ju, Jv);
             T2* dst = a.J + jIndex(p - a.p_begin, 0, C);
+            bool store = true;
+            if (a.nostore) {
+                T acc = T(0);
 #pragma unroll
-            for (int c = 0; c < C; ++c) { T2 t; t.x = Ju[c]; t.y = Jv[c]; dst[4 * c] = t; }
+                for (int c = 0; c < C; ++c) acc += Ju[c] + Jv[c];
+                store = acc != acc;      // never true for finite data; keeps the arithmetic live
+            }
+            if (store) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) { T2 t; t.x = Ju[c]; t.y = Jv[c]; dst[4 * c] = t; }
+            }
         } else {
             project_point<MODEL, T>(sp, vc, xy.x, xy.y, z, u, v);
         }
@@ -263,6 +273,134 @@ __global__ __launch_bounds__(256) void gram_kernel(const typename Pair<T>::type*
         for (int i = lane; i < 273; i += 64) {
             double t = sred[wave][i];
             for (int w = 1; w < wpi; ++w) t += sred[wave + w][i];
+            G[i] = t;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- fused jacobian + gram
+// The same per-item J^T J / J^T r / sum r^2 as jacobian_kernel + gram_kernel, without the compact
+// Jacobian ever leaving the CU: a wave evaluates 64 points (one per lane, closed-form 2 x C block
+// in registers), transposes 32 points at a time through its private LDS slab (rows padded to an
+// odd number of 16-B chunks: conflict-free ds_write_b128 / ds_read_b128) into the MFMA operand
+// map (lane (k, c) <- point 4s+k, column c) and feeds v_mfma_f64_16x16x4_f64. The view constants
+// are wave-uniform (scalar loads). HBM traffic per point: the 44 B of inputs.
+template <typename T> struct FusedCfg {
+    static constexpr int kRowChunks = 17;                 // 16 columns + 1 pad chunk (odd => conflict-free)
+    static constexpr int kSlabChunks = 32 * kRowChunks + 32;   // 32 points x row, + 32 residual pairs
+};
+
+template <int MODEL, typename T>
+__global__ __launch_bounds__(256) void fused_kernel(const double* __restrict__ P0, const double* __restrict__ P1,
+                                                    const typename Pair<T>::type* __restrict__ uv,
+                                                    const typename Pair<T>::type* __restrict__ XY,
+                                                    const T* __restrict__ Z, const T* __restrict__ VC,
+                                                    const int64_t* __restrict__ item_pt0,
+                                                    const int* __restrict__ item_n,
+                                                    const int* __restrict__ item_view, int n_items, int wpi,
+                                                    const LMState* __restrict__ st, int sel,
+                                                    double* __restrict__ G0, double* __restrict__ G1) {
+    using T2 = typename Pair<T>::type;
+    constexpr int C = ModelTraits<MODEL>::C;
+    constexpr int RS = FusedCfg<T>::kRowChunks;
+    constexpr int SLAB = FusedCfg<T>::kSlabChunks;
+    // one slab per wave; after the main loop the same memory holds the wave partial tiles
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * SLAB * sizeof(T2) > 4 * kGStride * 8
+                                                                     ? 4 * SLAB * sizeof(T2) : 4 * kGStride * 8];
+    if (sel && st->done) return;
+    const double* P = selectP(P0, P1, st, sel);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = wave % wpi;
+    const int item = blockIdx.x * (4 / wpi) + wave / wpi;
+    const bool valid = item < n_items;
+    const int c = lane & 15, k = lane >> 4;
+    const bool cvalid = c < C;
+    T2* slab = reinterpret_cast<T2*>(smem) + wave * SLAB;
+    T2* rslab = slab + 32 * RS;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    double gacc = 0.0, eacc = 0.0;
+    if (valid) {
+        const int64_t pbeg = item_pt0[item];
+        const int n = item_n[item];
+        const int per = ((n + 3) / 4 + wpi - 1) / wpi * 4;      // points per wave, multiple of 4
+        const int qbeg = sub * per;
+        const int qend = qbeg + per < n ? qbeg + per : n;
+        const T* vc = VC + (int64_t)__builtin_amdgcn_readfirstlane(item_view[item]) * kViewStride;
+        Shared<MODEL, T> sp;
+        sp.load(P);
+        for (int q0 = qbeg; q0 < qend; q0 += 64) {
+            const int q = q0 + lane;
+            const bool pvalid = q < qend;
+            const int64_t p = pbeg + (pvalid ? q : qend - 1);
+            const T2 m = uv[p];
+            const T2 xy = XY[p];
+            const T z = Z[p];
+            T u, v, Ju[C], Jv[C];
+            jacobian_point<MODEL, T>(sp, vc, xy.x, xy.y, z, u, v, Ju, Jv);
+            T2 res;
+            res.x = pvalid ? m.x - u : T(0);
+            res.y = pvalid ? m.y - v : T(0);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if (q0 + 32 * half >= qend) break;              // wave-uniform
+                __builtin_amdgcn_wave_barrier();
+                if ((lane >> 5) == half) {
+                    T2* row = slab + (lane & 31) * RS;
+#pragma unroll
+                    for (int cc = 0; cc < C; ++cc) {
+                        T2 t;
+                        t.x = pvalid ? Ju[cc] : T(0);
+                        t.y = pvalid ? Jv[cc] : T(0);
+                        row[cc] = t;
+                    }
+                    if (C < 16) { T2 t; t.x = T(0); t.y = T(0); row[15] = t; }
+                    rslab[lane & 31] = res;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int rows = qend - (q0 + 32 * half);       // valid points in this half (may exceed 32)
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    if (4 * s >= rows) break;                   // wave-uniform
+                    const T2 jv = slab[(4 * s + k) * RS + c];
+                    const T2 rv = rslab[4 * s + k];
+                    const double jx = (double)jv.x, jy = (double)jv.y;
+                    const double rx = (double)rv.x, ry = (double)rv.y;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jx, jx, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc, 0, 0, 0);
+                    gacc += jx * rx + jy * ry;
+                    eacc += rx * rx + ry * ry;
+                }
+            }
+        }
+        gacc += __shfl_xor(gacc, 16, 64);
+        gacc += __shfl_xor(gacc, 32, 64);
+        eacc += __shfl_xor(eacc, 16, 64);
+        eacc += __shfl_xor(eacc, 32, 64);
+    }
+    (void)cvalid;
+    double* Gbase = sel ? ((st->cur ^ 1) ? G1 : G0) : G0;
+    if (wpi == 1) {
+        if (!valid) return;
+        double* G = Gbase + (int64_t)item * kGStride;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) G[(k + 4 * reg) * 16 + c] = acc[reg];
+        if (k == 0) G[256 + c] = gacc;
+        if (lane == 0) G[272] = eacc;
+        return;
+    }
+    __syncthreads();                                            // slabs are dead, reuse as partial tiles
+    double* sred = reinterpret_cast<double*>(smem);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) sred[wave * kGStride + (k + 4 * reg) * 16 + c] = acc[reg];
+    if (k == 0) sred[wave * kGStride + 256 + c] = gacc;
+    if (lane == 0) sred[wave * kGStride + 272] = eacc;
+    __syncthreads();
+    if (sub == 0 && valid) {
+        double* G = Gbase + (int64_t)item * kGStride;
+        for (int i = lane; i < 273; i += 64) {
+            double t = sred[wave * kGStride + i];
+            for (int w = 1; w < wpi; ++w) t += sred[(wave + w) * kGStride + i];
             G[i] = t;
         }
     }

@@ -113,6 +113,11 @@ class RefineEngine:
         else:
             nat.check(self._lib.calib_set_stream(self._h, ctypes.c_void_p(int(hipStream)), 0))
 
+    def setLmMode(self, mode):
+        """'fused' (default) or 'two_kernel' (materialise the compact J in HBM), see calib_lm.h."""
+        ids = {"fused": nat.LM_FUSED, "two_kernel": nat.LM_TWO_KERNEL}
+        nat.check(self._lib.calib_set_lm_mode(self._h, ids[mode] if isinstance(mode, str) else int(mode)))
+
     def _P(self, P):
         P = np.ascontiguousarray(np.asarray(P, dtype=np.float64).ravel())
         if P.shape[0] != self.K:

@@ -72,6 +72,15 @@ int calib_set_stream(calib_handle_t h, void* hip_stream, int use_own);
 int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_offsets,
                       const double* sensor_uv, const double* model_xyz);
 
+/* How an LM round forms the per-view normal equations:
+ *   CALIB_LM_FUSED       one kernel evaluates the 2 x C Jacobian blocks and contracts them with
+ *                        MFMA without writing them to HBM (default; fastest);
+ *   CALIB_LM_TWO_KERNEL  the jacobian kernel materialises the compact J in HBM (the layout
+ *                        calib_eval returns) and the gram kernel reads it back.
+ * Both produce the same blocks (fixed, identical summation order per view item). */
+enum { CALIB_LM_FUSED = 0, CALIB_LM_TWO_KERNEL = 1 };
+int calib_set_lm_mode(calib_handle_t h, int mode);
+
 int calib_num_shared(calib_handle_t h, int* out_L);          /* L                          */
 int calib_num_params(calib_handle_t h, int64_t* out_K);       /* K = L + 6*num_views        */
 
@@ -137,8 +146,9 @@ int calib_distort_points(int model, int64_t n, const double* x_norm, const doubl
 int calib_project_with_distortion(int model, int64_t n, const double* A, const double* cam_xyz,
                                   const double* k, double* out_uv);
 
-/* HIP-event timing of the two dominant kernels over the rounds enqueued since the last
- * calib_profile_enable(h, 1). which: 0 = jacobian kernel, 1 = J^T J (MFMA) kernel. */
+/* HIP-event timing of the dominant kernels over the rounds enqueued since the last
+ * calib_profile_enable(h, 1). which: 0 = jacobian kernel, 1 = J^T J (MFMA) kernel,
+ * 2 = fused jacobian + J^T J kernel. */
 int calib_profile_enable(calib_handle_t h, int on);
 int calib_profile_read(calib_handle_t h, int which, double* out_total_ms, int64_t* out_launches);
 
