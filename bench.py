@@ -6,9 +6,10 @@ point-residuals/s on a synthetic checkerboard dataset).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = ONE LM iteration (src/calibrate.py:143-168) over the rank's resident views:
-per-point residual + Jacobian kernel, J^T J / J^T r MFMA kernel, per-view Schur
-elimination, (N > 1: one RCCL all-reduce of the reduce buffer), accept/reject + L x L
-solve, back-substitution. Termination tests are disabled for the timed region
+per-point residual + Jacobian blocks contracted to per-view J^T J / J^T r with MFMA (fused
+kernel; `--lm-mode two_kernel` materialises the compact J in HBM between a jacobian and a gram
+kernel instead), per-view Schur elimination, (N > 1: one RCCL all-reduce of the reduce
+buffer), accept/reject + L x L solve, back-substitution. Termination tests are disabled for the timed region
 (lam_min = 0, lam_max = inf, err_min = -inf) so that exactly K iterations execute, each
 with full work. Weak scaling: every rank holds `views` views of the config.
 One JSON line is printed by rank 0.
@@ -79,6 +80,7 @@ def main():
     ap.add_argument("--views", type=int, default=None, help="views per GPU (default: the config's)")
     ap.add_argument("--noise", type=float, default=0.1, help="sensor noise sigma in px")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lm-mode", default="fused", choices=["fused", "two_kernel"])
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,6 +117,7 @@ def main():
     t0 = time.perf_counter()
     eng.setProblem(shard["viewOffsets"], shard["sensorPoints"], shard["modelPoints"])
     tUpload = time.perf_counter() - t0
+    eng.setLmMode(args.lm_mode)
     lmOpts = dict(lamInit=1e-3, lamMin=0.0, lamMax=float("inf"), errMin=-float("inf"))
     total = args.warmup + args.steps
 
@@ -142,8 +145,31 @@ def main():
     elapsed = time.perf_counter() - t0
     jacMs, jacN = eng.profileRead(0)
     gramMs, gramN = eng.profileRead(1)
+    fusedMs, fusedN = eng.profileRead(2)
     eng.profileEnable(False)
     sse, P, iters, trace = eng.lmEnd()
+    if rank == 0 and args.lm_mode == "fused":
+        # the same shard through the two-kernel path (compact J through HBM), timed for the
+        # HBM roofline of the jacobian kernel and the gram kernel; not part of `value`
+        eng2 = cca.RefineEngine(cfg["model"], cfg["dtype"], local)
+        eng2.setProblem(shard["viewOffsets"], shard["sensorPoints"], shard["modelPoints"])
+        eng2.setLmMode("two_kernel")
+        eng2.lmBegin(shard["P0"], 16, **lmOpts)
+        eng2.lmRun(4)
+        eng2.lmDone()
+        eng2.profileEnable(True)
+        t2 = time.perf_counter()
+        eng2.lmRun(10)
+        eng2.lmDone()
+        twoKernelMsPerStep = (time.perf_counter() - t2) / 10 * 1e3
+        jacMs, jacN = eng2.profileRead(0)
+        gramMs, gramN = eng2.profileRead(1)
+        jacSteps = gramSteps = 10
+        eng2.lmEnd()
+        eng2.close()
+    else:
+        twoKernelMsPerStep = None
+        jacSteps = gramSteps = args.steps
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -162,20 +188,40 @@ def main():
         jacAvgMs = jacMs / max(jacN, 1)
         gramAvgMs = gramMs / max(gramN, 1)
         # a launch covers one chunk of whole views: points per launch = points x steps / launches
-        jacPts = MNlocal * args.steps / max(jacN, 1)
-        gramPts = MNlocal * args.steps / max(gramN, 1)
+        jacPts = MNlocal * jacSteps / max(jacN, 1)
+        gramPts = MNlocal * gramSteps / max(gramN, 1)
         jacGBs = jacBytes * jacPts / (jacAvgMs * 1e-3) / 1e9 if jacN else None
         gramGBs = gramBytes * gramPts / (gramAvgMs * 1e-3) / 1e9 if gramN else None
         C = L + 6
         gramFlops = (4 * 16 * 16 + 4 * C) * gramPts      # as executed on full 16x16 MFMA tiles + J^T r
         accepted = int(trace[args.warmup:, 4].sum()) if trace.shape[0] > args.warmup else 0
-        traffic = None
+        pmc = {}
         trafficFile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(trafficFile):
             try:
-                traffic = json.load(open(trafficFile)).get(args.workload, {}).get("jacobian_bytes_per_launch")
+                pmc = json.load(open(trafficFile)).get(args.workload, {})
             except Exception:
-                traffic = None
+                pmc = {}
+        traffic = pmc.get("jacobian_bytes_per_launch")
+        jacRoof = {"kernel": "jacobian_kernel (two-kernel mode)", "bound": "hbm",
+                   "achieved": jacGBs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": (jacGBs / HBM_PEAK_GBS) if jacGBs else None, "traffic": traffic,
+                   "algorithmic_bytes_per_launch": jacBytes * jacPts, "points_per_launch": jacPts,
+                   "launches_per_step": jacN / jacSteps,
+                   "avg_launch_ms": jacAvgMs, "launches_timed": jacN}
+        if fusedN:
+            fusedAvgMs = fusedMs / fusedN
+            fusedPts = MNlocal * args.steps / fusedN
+            mfmaFlops = 4 * 16 * 16 * fusedPts               # 2 x v_mfma_f64_16x16x4 (2048 flop) per 4 points
+            tf = mfmaFlops / (fusedAvgMs * 1e-3) / 1e12
+            mainRoof = {"kernel": "fused_kernel (jacobian blocks + v_mfma_f64_16x16x4_f64 J^T J, J on-chip)",
+                        "bound": "mfma", "achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tf / FP64_MATRIX_PEAK_TFLOPS, "traffic": pmc.get("fused_bytes_per_launch"),
+                        "mfma_flops_per_launch": mfmaFlops, "points_per_launch": fusedPts,
+                        "algorithmic_hbm_bytes_per_launch": (5 * w + 4) * fusedPts,
+                        "avg_launch_ms": fusedAvgMs, "launches_timed": fusedN}
+        else:
+            mainRoof = jacRoof
         out = {
             "metric": "LM point-residuals/sec (and LM iters/sec), synthetic checkerboard, views sharded over GPUs",
             "value": MNglobal * args.steps / elapsed,
@@ -188,20 +234,18 @@ def main():
             "config": {"workload": f"{args.workload}: {viewsPerGpu} views x {shard['pointsPerView']} pts per GPU, "
                                    f"{cfg['model']}, {cfg['dtype']}, sensor noise {args.noise} px",
                        "views_per_gpu": viewsPerGpu, "points_per_view": shard["pointsPerView"],
-                       "global_points": MNglobal, "model": cfg["model"], "parallelism": f"views-sharded x{world}"},
-            "roofline": {"kernel": "jacobian_kernel", "bound": "hbm",
-                         "achieved": jacGBs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (jacGBs / HBM_PEAK_GBS) if jacGBs else None, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": jacBytes * jacPts, "points_per_launch": jacPts,
-                         "launches_per_step": jacN / args.steps,
-                         "avg_launch_ms": jacAvgMs, "launches_timed": jacN},
-            "roofline_gram": {"kernel": "gram_kernel (v_mfma_f64_16x16x4_f64)", "bound": "hbm",
+                       "global_points": MNglobal, "model": cfg["model"], "parallelism": f"views-sharded x{world}",
+                       "lm_mode": args.lm_mode},
+            "roofline": mainRoof,
+            "roofline_jacobian_kernel": jacRoof,
+            "two_kernel_ms_per_step": twoKernelMsPerStep,
+            "roofline_gram": {"kernel": "gram_kernel (two-kernel mode, v_mfma_f64_16x16x4_f64)", "bound": "hbm",
                               "achieved": gramGBs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": (gramGBs / HBM_PEAK_GBS) if gramGBs else None,
                               "mfma_tflops": gramFlops / (gramAvgMs * 1e-3) / 1e12 if gramN else None,
                               "mfma_peak_tflops": FP64_MATRIX_PEAK_TFLOPS,
                               "mfma_util": gramFlops / (gramAvgMs * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS if gramN else None,
-                              "points_per_launch": gramPts, "launches_per_step": gramN / args.steps,
+                              "points_per_launch": gramPts, "launches_per_step": gramN / gramSteps,
                               "avg_launch_ms": gramAvgMs, "launches_timed": gramN},
             "lm": {"accepted_steps_in_timed_region": accepted, "final_sse": sse,
                    "max_rel_err_intrinsics_vs_truth": float(np.max(np.abs(P[:L] - shard["Ptrue"][:L])

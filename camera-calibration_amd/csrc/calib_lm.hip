@@ -201,14 +201,23 @@ template <int MODEL, typename T>
 int launch_fused_t(calib_handle_s* h, const LMState* st, int sel) {
     using T2 = typename Pair<T>::type;
     if (h->n_items == 0) return CALIB_OK;
-    const int ipb = 4 / h->fused_wpi;
-    const int blocks = (h->n_items + ipb - 1) / ipb;
+    static const int variant = std::getenv("CALIB_FUSED_VARIANT") ? std::atoi(std::getenv("CALIB_FUSED_VARIANT")) : 0;
     int pi = prof_begin(h, 2);
-    hipLaunchKernelGGL((fused_kernel<MODEL, T>), dim3(blocks), dim3(256), 0, h->stream, h->P[0].p, h->P[1].p,
-                       reinterpret_cast<const T2*>(h->uv.p), reinterpret_cast<const T2*>(h->XY.p),
-                       reinterpret_cast<const T*>(h->Z.p), reinterpret_cast<const T*>(h->VC.p),
-                       h->item_pt0.p, h->item_n.p, h->item_view.p, h->n_items, h->fused_wpi, st, sel,
-                       h->G[0].p, h->G[1].p);
+#define CALIB_LAUNCH_FUSED(ROWS, WAVES)                                                                      \
+    do {                                                                                                     \
+        const int wpi = std::min(h->fused_wpi, WAVES);                                                       \
+        const int ipb = WAVES / wpi;                                                                         \
+        const int blocks = (h->n_items + ipb - 1) / ipb;                                                     \
+        hipLaunchKernelGGL((fused_kernel<MODEL, T, ROWS, WAVES>), dim3(blocks), dim3(64 * WAVES), 0,         \
+                           h->stream, h->P[0].p, h->P[1].p, reinterpret_cast<const T2*>(h->uv.p),            \
+                           reinterpret_cast<const T2*>(h->XY.p), reinterpret_cast<const T*>(h->Z.p),         \
+                           reinterpret_cast<const T*>(h->VC.p), h->item_pt0.p, h->item_n.p, h->item_view.p,  \
+                           h->n_items, wpi, st, sel, h->G[0].p, h->G[1].p);                                  \
+    } while (0)
+    if (variant == 1) CALIB_LAUNCH_FUSED(64, 2);
+    else if (variant == 2) CALIB_LAUNCH_FUSED(32, 2);
+    else CALIB_LAUNCH_FUSED(32, 4);
+#undef CALIB_LAUNCH_FUSED
     prof_end(h, pi);
     HIP_TRY(hipGetLastError());
     return CALIB_OK;

@@ -285,13 +285,12 @@ __global__ __launch_bounds__(256) void gram_kernel(const typename Pair<T>::type*
 // odd number of 16-B chunks: conflict-free ds_write_b128 / ds_read_b128) into the MFMA operand
 // map (lane (k, c) <- point 4s+k, column c) and feeds v_mfma_f64_16x16x4_f64. The view constants
 // are wave-uniform (scalar loads). HBM traffic per point: the 44 B of inputs.
-template <typename T> struct FusedCfg {
-    static constexpr int kRowChunks = 17;                 // 16 columns + 1 pad chunk (odd => conflict-free)
-    static constexpr int kSlabChunks = 32 * kRowChunks + 32;   // 32 points x row, + 32 residual pairs
-};
+constexpr int kFusedRowChunks = 17;                       // 16 columns + 1 pad chunk (odd => conflict-free)
 
-template <int MODEL, typename T>
-__global__ __launch_bounds__(256) void fused_kernel(const double* __restrict__ P0, const double* __restrict__ P1,
+// ROWS = points transposed per LDS pass (32: two passes per 64-point batch, half the lanes
+// writing each time; 64: one pass, twice the LDS). WAVES = waves per workgroup.
+template <int MODEL, typename T, int ROWS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restrict__ P0, const double* __restrict__ P1,
                                                     const typename Pair<T>::type* __restrict__ uv,
                                                     const typename Pair<T>::type* __restrict__ XY,
                                                     const T* __restrict__ Z, const T* __restrict__ VC,
@@ -302,22 +301,23 @@ __global__ __launch_bounds__(256) void fused_kernel(const double* __restrict__ P
                                                     double* __restrict__ G0, double* __restrict__ G1) {
     using T2 = typename Pair<T>::type;
     constexpr int C = ModelTraits<MODEL>::C;
-    constexpr int RS = FusedCfg<T>::kRowChunks;
-    constexpr int SLAB = FusedCfg<T>::kSlabChunks;
+    constexpr int RS = kFusedRowChunks;
+    constexpr int SLAB = ROWS * RS + ROWS;                 // ROWS point rows + ROWS residual pairs
+    constexpr int HALVES = 64 / ROWS;
     // one slab per wave; after the main loop the same memory holds the wave partial tiles
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * SLAB * sizeof(T2) > 4 * kGStride * 8
-                                                                     ? 4 * SLAB * sizeof(T2) : 4 * kGStride * 8];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WAVES * SLAB * sizeof(T2) > WAVES * kGStride * 8
+                                                                     ? WAVES * SLAB * sizeof(T2) : WAVES * kGStride * 8];
     if (sel && st->done) return;
     const double* P = selectP(P0, P1, st, sel);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sub = wave % wpi;
-    const int item = blockIdx.x * (4 / wpi) + wave / wpi;
+    const int item = blockIdx.x * (WAVES / wpi) + wave / wpi;
     const bool valid = item < n_items;
     const int c = lane & 15, k = lane >> 4;
     const bool cvalid = c < C;
     T2* slab = reinterpret_cast<T2*>(smem) + wave * SLAB;
-    T2* rslab = slab + 32 * RS;
+    T2* rslab = slab + ROWS * RS;
     d4 acc = {0.0, 0.0, 0.0, 0.0};
     double gacc = 0.0, eacc = 0.0;
     if (valid) {
@@ -329,24 +329,30 @@ __global__ __launch_bounds__(256) void fused_kernel(const double* __restrict__ P
         const T* vc = VC + (int64_t)__builtin_amdgcn_readfirstlane(item_view[item]) * kViewStride;
         Shared<MODEL, T> sp;
         sp.load(P);
+        // inputs of the next batch are requested before the current batch is evaluated
+        int64_t pn = pbeg + (qbeg + lane < qend ? qbeg + lane : qend - 1);
+        T2 m_n = uv[pn], xy_n = XY[pn];
+        T z_n = Z[pn];
         for (int q0 = qbeg; q0 < qend; q0 += 64) {
             const int q = q0 + lane;
             const bool pvalid = q < qend;
-            const int64_t p = pbeg + (pvalid ? q : qend - 1);
-            const T2 m = uv[p];
-            const T2 xy = XY[p];
-            const T z = Z[p];
+            const T2 m = m_n, xy = xy_n;
+            const T z = z_n;
+            if (q0 + 64 < qend) {
+                pn = pbeg + (q + 64 < qend ? q + 64 : qend - 1);
+                m_n = uv[pn]; xy_n = XY[pn]; z_n = Z[pn];
+            }
             T u, v, Ju[C], Jv[C];
             jacobian_point<MODEL, T>(sp, vc, xy.x, xy.y, z, u, v, Ju, Jv);
             T2 res;
             res.x = pvalid ? m.x - u : T(0);
             res.y = pvalid ? m.y - v : T(0);
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                if (q0 + 32 * half >= qend) break;              // wave-uniform
+            for (int half = 0; half < HALVES; ++half) {
+                if (q0 + ROWS * half >= qend) break;            // wave-uniform
                 __builtin_amdgcn_wave_barrier();
-                if ((lane >> 5) == half) {
-                    T2* row = slab + (lane & 31) * RS;
+                if (HALVES == 1 || (lane >> 5) == half) {
+                    T2* row = slab + (lane & (ROWS - 1)) * RS;
 #pragma unroll
                     for (int cc = 0; cc < C; ++cc) {
                         T2 t;
@@ -355,12 +361,12 @@ __global__ __launch_bounds__(256) void fused_kernel(const double* __restrict__ P
                         row[cc] = t;
                     }
                     if (C < 16) { T2 t; t.x = T(0); t.y = T(0); row[15] = t; }
-                    rslab[lane & 31] = res;
+                    rslab[lane & (ROWS - 1)] = res;
                 }
                 __builtin_amdgcn_wave_barrier();
-                const int rows = qend - (q0 + 32 * half);       // valid points in this half (may exceed 32)
+                const int rows = qend - (q0 + ROWS * half);     // valid points in this pass (may exceed ROWS)
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
+                for (int s = 0; s < ROWS / 4; ++s) {
                     if (4 * s >= rows) break;                   // wave-uniform
                     const T2 jv = slab[(4 * s + k) * RS + c];
                     const T2 rv = rslab[4 * s + k];

@@ -233,3 +233,29 @@ def test_one_big_view_spans_many_gram_items():
     do = orc.lmStepSchur(orc.RADTAN, P0, offs, s, corners, 1e-3)
     assert np.linalg.norm(d - do) / np.linalg.norm(do) < 1e-8
     eng.close()
+
+
+@pytest.mark.parametrize("tag,name", [("g3_unittest15.npz", "radtan"), ("g2_config1_fisheye.npz", "fisheye")])
+def test_fused_and_two_kernel_modes_agree(tag, name):
+    """CALIB_LM_FUSED (J stays on the CU) and CALIB_LM_TWO_KERNEL (compact J through HBM) build the
+    same per-view normal equations and take the same LM path."""
+    g = loadGolden(tag)
+    P0 = g["P0"]
+    out = {}
+    for mode in ("fused", "two_kernel"):
+        eng = makeEngine(name, g)
+        eng.setLmMode(mode)
+        B, E, V, gg = eng.normalEquations(P0)
+        d = eng.stepDelta(P0, 1e-3)
+        sse, P, iters, trace = eng.refine(P0, 100)
+        out[mode] = (B, E, V, gg, d, sse, P, iters, trace)
+        eng.close()
+    a, b = out["fused"], out["two_kernel"]
+    for x, y in zip(a[:4], b[:4]):
+        assert np.abs(x - y).max() <= 1e-13 * np.abs(y).max()
+    assert np.linalg.norm(a[4] - b[4]) <= 1e-10 * np.linalg.norm(b[4])
+    assert a[7] == b[7] or abs(a[7] - b[7]) <= 2
+    n = min(5, a[7], b[7])
+    assert np.array_equal(a[8][:n, 3], b[8][:n, 3])
+    assert np.abs(a[6][:10] - b[6][:10]).max() < 1e-9
+    assert np.abs(a[6][:10] - g["Pfinal"][:10]).max() < 1e-9

@@ -1,3 +1,8 @@
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print(d["config"]["workload"][:30], "value %.3e ms/step %.4f jac %.4f ms frac %.3f gram %.4f ms frac %.3f" % (d["value"], d["ms_per_step"], d["roofline"]["avg_launch_ms"]*d["roofline"].get("launches_per_step",1), d["roofline"]["frac"], d["roofline_gram"]["avg_launch_ms"]*d["roofline_gram"].get("launches_per_step",1), d["roofline_gram"]["frac"]))
+import json, sys
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+r, j, g = d["roofline"], d.get("roofline_jacobian_kernel") or {}, d.get("roofline_gram") or {}
+def ms(x):
+    return (x.get("avg_launch_ms") or 0) * (x.get("launches_per_step") or 1)
+print(d["config"]["workload"][:34], "| value %.3e ms/step %.4f | main[%s] %.4f ms frac %.3f | two-kernel %s ms/step: jac %.4f ms frac %s gram %.4f ms frac %s"
+      % (d["value"], d["ms_per_step"], r["bound"], ms(r), r["frac"] or 0, d.get("two_kernel_ms_per_step"),
+         ms(j), j.get("frac"), ms(g), g.get("frac")))

@@ -67,10 +67,12 @@ def main():
         traffic = json.load(open(tf)) if os.path.exists(tf) else {}
         jac = [v for k, v in summary.items() if k.startswith("jacobian_kernel")]
         gram = [v for k, v in summary.items() if k.startswith("gram_kernel")]
+        fused = [v for k, v in summary.items() if k.startswith("fused_kernel")]
         traffic[a.workload] = {
             "source": f"profiles/{a.tag}_pmc.json",
             "jacobian_bytes_per_launch": max(v["hbm_bytes_per_launch"] for v in jac) if jac else None,
             "gram_bytes_per_launch": max(v["hbm_bytes_per_launch"] for v in gram) if gram else None,
+            "fused_bytes_per_launch": max(v["hbm_bytes_per_launch"] for v in fused) if fused else None,
         }
         json.dump(traffic, open(tf, "w"), indent=1)
         print(json.dumps(traffic[a.workload]))
