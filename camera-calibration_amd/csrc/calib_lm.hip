@@ -236,10 +236,10 @@ int launch_schur_reduce(calib_handle_s* h, const LMState* st, double* red) {
     if (h->nv > 0) {
         dim3 grid(h->schur_blocks, 2);
         if (h->L == 10)
-            hipLaunchKernelGGL((schur_kernel<10>), grid, dim3(kSchurThreads), 0, h->stream, h->G[0].p,
+            hipLaunchKernelGGL((schur_kernel<10>), grid, dim3(kSchurBlock), 0, h->stream, h->G[0].p,
                                h->G[1].p, st, h->view_item0.p, h->nv, h->part.p);
         else
-            hipLaunchKernelGGL((schur_kernel<9>), grid, dim3(kSchurThreads), 0, h->stream, h->G[0].p,
+            hipLaunchKernelGGL((schur_kernel<9>), grid, dim3(kSchurBlock), 0, h->stream, h->G[0].p,
                                h->G[1].p, st, h->view_item0.p, h->nv, h->part.p);
         HIP_TRY(hipGetLastError());
     }
@@ -459,7 +459,7 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
         }
     }
     h->max_views_per_tile = mv;
-    const int per = kSchurThreads / 16;
+    const int per = kSchurViewsPerBlock;
     h->schur_blocks = std::max(1, std::min(kMaxSchurBlocks, (h->nv + per - 1) / per));
 
     const size_t ts = tsize(h);

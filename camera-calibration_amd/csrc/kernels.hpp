@@ -61,6 +61,8 @@ struct LMState {
     int accepted_last;
     int pad;
     double dc[kMaxL];
+    double B[kMaxL * kMaxL];   // sum_views J_s^T J_s and
+    double gc[kMaxL];          // sum_views J_s^T r at the CURRENT parameters (variant B re-uses them)
 };
 
 // reduce-buffer layout (doubles): two variants of
@@ -483,74 +485,139 @@ __device__ __forceinline__ void eliminate(const double (&col)[16], double gc, do
 // ---------------------------------------------------------------- schur partials
 // grid (nblocks, 2): y = 0 variant A (candidate blocks, lambda_accept),
 //                    y = 1 variant B (current blocks, lambda_reject).
+// 16 lanes per view, 4 views per wave and trip. Every lane factors the view's damped 6x6 block
+// Vh = Lc Lc^T (loaded by broadcast), lane c < L forward-substitutes its row of E (z_c = Lc^-1 E_c),
+// lane L the view gradient (z_g = Lc^-1 g_v). Then sum_views E Vh^-1 [E^T | g_v] = W^T W with
+// W = [z_0 .. z_{L-1} z_g] is one more tall-skinny Gram: 6 x v_mfma_f64_16x16x4_f64 per trip,
+// K-slot = view, no cross-lane traffic. B, g_c, sum r^2 are plain per-lane sums (variant A only).
+constexpr int kSchurBlock = 256;
+constexpr int kSchurViewsPerBlock = kSchurBlock / 16;
+
 template <int L>
-__global__ __launch_bounds__(kSchurThreads) void schur_kernel(const double* __restrict__ G0,
-                                                              const double* __restrict__ G1,
-                                                              const LMState* __restrict__ st,
-                                                              const int* __restrict__ view_item0,
-                                                              int nv, double* __restrict__ part) {
+__global__ __launch_bounds__(kSchurBlock) void schur_kernel(const double* __restrict__ G0,
+                                                            const double* __restrict__ G1,
+                                                            const LMState* __restrict__ st,
+                                                            const int* __restrict__ view_item0,
+                                                            int nv, double* __restrict__ part) {
     constexpr int VA = variantSize(L);
-    constexpr int NACC = 2 * L + 4;
-    __shared__ double sacc[kSchurThreads / 16][16][NACC];
+    constexpr int NACC = L + 3;                               // B column sums, g_c, nfail, sse
+    __shared__ double sacc[kSchurViewsPerBlock][16][NACC];
+    __shared__ double stile[kSchurBlock / 64][256];
     if (st->done) return;
     const int variant = blockIdx.y;
-    const int tid = threadIdx.x, c = tid & 15, grp = tid >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = tid & 15, grp = tid >> 4, k = lane >> 4;
     double* out = part + ((int64_t)variant * gridDim.x + blockIdx.x) * VA;
     const bool boot = st->round == 0;
     if (variant == 1 && boot) {       // no "current" blocks yet
-        for (int i = tid; i < VA; i += kSchurThreads) out[i] = 0.0;
+        for (int i = tid; i < VA; i += kSchurBlock) out[i] = 0.0;
         return;
     }
     const int cand = st->cur ^ 1;
     const int buf = variant == 0 ? cand : st->cur;
     const double* G = buf ? G1 : G0;
     const double lam = variant == 0 ? (boot ? st->lam : st->lam / 10) : st->lam * 10;
+    const bool sums = variant == 0;                           // variant B re-uses the state's B, g_c, err
 
-    double Bacc[L], Sacc[L], gacc = 0.0, sac = 0.0, nfail = 0.0, eacc = 0.0;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    double Bacc[L], gacc = 0.0, nfail = 0.0, eacc = 0.0;
 #pragma unroll
-    for (int i = 0; i < L; ++i) { Bacc[i] = 0.0; Sacc[i] = 0.0; }
-    const int groupsPerBlock = kSchurThreads / 16;
-    for (int v = blockIdx.x * groupsPerBlock + grp; v < nv; v += gridDim.x * groupsPerBlock) {
-        double col[16], gc, sse;
-        const int i0 = view_item0[v];
-        load_view_col(G, i0, view_item0[v + 1] - i0, c, col, gc, sse);
-        Elim<L> e;
-        eliminate<L>(col, gc, lam, e);
-        eacc += sse;
-        double dzg = 0.0;
+    for (int i = 0; i < L; ++i) Bacc[i] = 0.0;
+    for (int v0 = blockIdx.x * kSchurViewsPerBlock; v0 < nv; v0 += gridDim.x * kSchurViewsPerBlock) {
+        const int v = v0 + grp;
+        double z[6];
 #pragma unroll
-        for (int m = 0; m < 6; ++m) dzg += e.z[m] * e.zg[m];
+        for (int m = 0; m < 6; ++m) z[m] = 0.0;
+        if (v < nv) {                                         // whole 16-lane group together
+            const int i0 = view_item0[v], i1 = view_item0[v + 1];
+            double V[21], b[6];
 #pragma unroll
-        for (int cc = 0; cc < L; ++cc) {
-            double t = 0.0;
+            for (int i = 0; i < 21; ++i) V[i] = 0.0;
 #pragma unroll
-            for (int m = 0; m < 6; ++m) t += e.z[m] * __shfl(e.z[m], cc, 16);
-            Sacc[cc] += t;
-            Bacc[cc] += col[cc];
+            for (int m = 0; m < 6; ++m) b[m] = 0.0;
+            for (int it = i0; it < i1; ++it) {                // > 1 item only for views above kGramChunk points
+                const double* g = G + (int64_t)it * kGStride;
+#pragma unroll
+                for (int m = 0; m < 6; ++m) {
+#pragma unroll
+                    for (int n = 0; n <= m; ++n) V[tri(m, n)] += g[(L + m) * 16 + L + n];
+                    // lane c < L: E[c][m] = G[L+m][c]; lane L: g_v[m]; lanes above: nothing
+                    const double* src = c < L ? g + (L + m) * 16 + c : g + 256 + L + m;
+                    const double t = *src;
+                    b[m] += c <= L ? t : 0.0;
+                }
+                if (sums) {
+                    if (c < L) {
+#pragma unroll
+                        for (int rr = 0; rr < L; ++rr) Bacc[rr] += g[rr * 16 + c];
+                        gacc += g[256 + c];
+                    }
+                    if (c == 0) eacc += g[272];
+                }
+            }
+            // Cholesky of V + lam diag(V)  (JTJ + lam * diag(JTJ), src/calibrate.py:147,152), in place
+            double invd[6];
+            bool fail = false;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                double d = V[tri(j, j)] + lam * V[tri(j, j)];
+#pragma unroll
+                for (int q = 0; q < j; ++q) d -= V[tri(j, q)] * V[tri(j, q)];
+                if (!(d > 0.0)) fail = true;
+                const double inv = 1.0 / sqrt(d);
+                invd[j] = inv;
+#pragma unroll
+                for (int i = j + 1; i < 6; ++i) {
+                    double t = V[tri(i, j)];
+#pragma unroll
+                    for (int q = 0; q < j; ++q) t -= V[tri(i, q)] * V[tri(j, q)];
+                    V[tri(i, j)] = t * inv;
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                double t = b[m];
+#pragma unroll
+                for (int n = 0; n < m; ++n) t -= V[tri(m, n)] * z[n];
+                z[m] = t * invd[m];
+            }
+            if (fail && c == 0) nfail += 1.0;
         }
-        gacc += gc;
-        sac += dzg;
-        if (e.fail) nfail += 1.0;
+        // W^T W: K-slot k = this lane's view, six rows per view
+#pragma unroll
+        for (int m = 0; m < 6; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(z[m], z[m], acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < L; ++i) { sacc[grp][c][i] = Bacc[i]; sacc[grp][c][L + i] = Sacc[i]; }
-    sacc[grp][c][2 * L] = gacc;
-    sacc[grp][c][2 * L + 1] = sac;
-    sacc[grp][c][2 * L + 2] = nfail;
-    sacc[grp][c][2 * L + 3] = eacc;
+    for (int reg = 0; reg < 4; ++reg) stile[wave][(k + 4 * reg) * 16 + c] = acc[reg];
+    if (sums) {
+#pragma unroll
+        for (int i = 0; i < L; ++i) sacc[grp][c][i] = Bacc[i];
+        sacc[grp][c][L] = gacc;
+        sacc[grp][c][L + 2] = eacc;
+    }
+    sacc[grp][c][L + 1] = nfail;
     __syncthreads();
-    if (grp == 0 && c < L) {
-        double t[NACC];
-#pragma unroll
-        for (int i = 0; i < NACC; ++i) t[i] = 0.0;
-        for (int g = 0; g < groupsPerBlock; ++g)
-#pragma unroll
-            for (int i = 0; i < NACC; ++i) t[i] += sacc[g][c][i];
-#pragma unroll
-        for (int i = 0; i < L; ++i) { out[c * L + i] = t[i]; out[L * L + c * L + i] = t[L + i]; }
-        out[2 * L * L + c] = t[2 * L];
-        out[2 * L * L + L + c] = t[2 * L + 1];
-        if (c == 0) { out[2 * L * L + 2 * L] = t[2 * L + 2]; out[2 * L * L + 2 * L + 1] = t[2 * L + 3]; }
+    // fixed-order sums over the block's waves / view groups
+    for (int i = tid; i < L * L; i += kSchurBlock) {
+        const int row = i / L, col = i - row * L;
+        double t = 0.0;
+        for (int w = 0; w < kSchurBlock / 64; ++w) t += stile[w][row * 16 + col];
+        out[L * L + i] = t;                                   // sum E Vh^-1 E^T
+        double bsum = 0.0;
+        if (sums) for (int g = 0; g < kSchurViewsPerBlock; ++g) bsum += sacc[g][row][col];   // B[row][col] = G[col][row]
+        out[i] = bsum;
+    }
+    if (tid < L) {
+        double t = 0.0, gs = 0.0;
+        for (int w = 0; w < kSchurBlock / 64; ++w) t += stile[w][tid * 16 + L];
+        if (sums) for (int g = 0; g < kSchurViewsPerBlock; ++g) gs += sacc[g][tid][L];
+        out[2 * L * L + tid] = gs;                            // g_c
+        out[2 * L * L + L + tid] = t;                         // sum E Vh^-1 g_v
+    }
+    if (tid == 0) {
+        double nf = 0.0, e = 0.0;
+        for (int g = 0; g < kSchurViewsPerBlock; ++g) { nf += sacc[g][0][L + 1]; if (sums) e += sacc[g][0][L + 2]; }
+        out[2 * L * L + 2 * L] = nf;
+        out[2 * L * L + 2 * L + 1] = e;
     }
 }
 
@@ -635,17 +702,31 @@ __global__ __launch_bounds__(64) void update_kernel(LMState* __restrict__ st, co
     if (done) return;
     if (sys[kNfail] > 0.0) { if (lane == 0) { st->error = -3; st->done = 1; } return; }
 
+    // B and g_c of the parameters the step starts from: variant A carries them for a freshly
+    // accepted (or the bootstrap) point, which also becomes the state's copy; after a rejection
+    // the state's copy of the unchanged current point is used.
+    const bool fresh = sys == red;
+    const double* Bm = fresh ? red : st->B;
+    const double* gcv = fresh ? red + 2 * L * L : st->gc;
     // row i of S = B + lam diag(B) - sum E Vh^-1 E^T, rhs s = g_c - sum E Vh^-1 g_v
     double row[L + 1];
 #pragma unroll
     for (int j = 0; j <= L; ++j) row[j] = 0.0;
     if (i < L) {
+        double brow[L];
 #pragma unroll
-        for (int j = 0; j < L; ++j) row[j] = sys[i * L + j] - sys[L * L + i * L + j];
-        row[L] = sys[2 * L * L + i] - sys[2 * L * L + L + i];
-        const double bii = sys[i * L + i];
+        for (int j = 0; j < L; ++j) brow[j] = Bm[i * L + j];
+        const double gci = gcv[i];
 #pragma unroll
-        for (int j = 0; j < L; ++j) if (j == i) row[j] += lam * bii;
+        for (int j = 0; j < L; ++j) row[j] = brow[j] - sys[L * L + i * L + j];
+        row[L] = gci - sys[2 * L * L + L + i];
+#pragma unroll
+        for (int j = 0; j < L; ++j) if (j == i) row[j] += lam * brow[j];
+        if (fresh && writer) {
+#pragma unroll
+            for (int j = 0; j < L; ++j) st->B[i * L + j] = brow[j];
+            st->gc[i] = gci;
+        }
     }
     bool used = false, singular = false;
     int myCol = -1;
