@@ -143,10 +143,6 @@ int launch_jacobian_t(calib_handle_s* h, const double* P0, const double* P1, con
     a.r = wantR ? reinterpret_cast<T2*>(h->r.p) : nullptr;
     a.y = wantY ? reinterpret_cast<T2*>(h->y.p) : nullptr;
     a.sse_part = wantSse ? h->sse_part.p : nullptr;
-    a.nostore = std::getenv("CALIB_JAC_NOSTORE") ? 1 : 0;
-    if (a.nostore && sel) {     // timing experiment only: keep evaluating P[0] whatever the LM state says
-        a.sel = 0; a.st = h->st_eval.p;
-    }
     const size_t lds = 32 + (size_t)h->max_views_per_tile * kViewStride * sizeof(T);
     int pi = prof_begin(h, 0);
     const unsigned tiles = (unsigned)((p_end - p_begin + kTile - 1) / kTile);
@@ -201,23 +197,15 @@ template <int MODEL, typename T>
 int launch_fused_t(calib_handle_s* h, const LMState* st, int sel) {
     using T2 = typename Pair<T>::type;
     if (h->n_items == 0) return CALIB_OK;
-    static const int variant = std::getenv("CALIB_FUSED_VARIANT") ? std::atoi(std::getenv("CALIB_FUSED_VARIANT")) : 0;
+    // ROWS = 32, 4 waves per workgroup: the 64-row / 2-wave variants measured 1-6 % slower (c3, c5, c2)
+    const int wpi = std::min(h->fused_wpi, 4);
+    const int ipb = 4 / wpi;
+    const int blocks = (h->n_items + ipb - 1) / ipb;
     int pi = prof_begin(h, 2);
-#define CALIB_LAUNCH_FUSED(ROWS, WAVES)                                                                      \
-    do {                                                                                                     \
-        const int wpi = std::min(h->fused_wpi, WAVES);                                                       \
-        const int ipb = WAVES / wpi;                                                                         \
-        const int blocks = (h->n_items + ipb - 1) / ipb;                                                     \
-        hipLaunchKernelGGL((fused_kernel<MODEL, T, ROWS, WAVES>), dim3(blocks), dim3(64 * WAVES), 0,         \
-                           h->stream, h->P[0].p, h->P[1].p, reinterpret_cast<const T2*>(h->uv.p),            \
-                           reinterpret_cast<const T2*>(h->XY.p), reinterpret_cast<const T*>(h->Z.p),         \
-                           reinterpret_cast<const T*>(h->VC.p), h->item_pt0.p, h->item_n.p, h->item_view.p,  \
-                           h->n_items, wpi, st, sel, h->G[0].p, h->G[1].p);                                  \
-    } while (0)
-    if (variant == 1) CALIB_LAUNCH_FUSED(64, 2);
-    else if (variant == 2) CALIB_LAUNCH_FUSED(32, 2);
-    else CALIB_LAUNCH_FUSED(32, 4);
-#undef CALIB_LAUNCH_FUSED
+    hipLaunchKernelGGL((fused_kernel<MODEL, T, 32, 4>), dim3(blocks), dim3(256), 0, h->stream, h->P[0].p,
+                       h->P[1].p, reinterpret_cast<const T2*>(h->uv.p), reinterpret_cast<const T2*>(h->XY.p),
+                       reinterpret_cast<const T*>(h->Z.p), reinterpret_cast<const T*>(h->VC.p), h->item_pt0.p,
+                       h->item_n.p, h->item_view.p, h->n_items, wpi, st, sel, h->G[0].p, h->G[1].p);
     prof_end(h, pi);
     HIP_TRY(hipGetLastError());
     return CALIB_OK;

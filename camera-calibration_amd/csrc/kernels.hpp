@@ -120,7 +120,6 @@ struct JacArgs {
     T2* r;        // [MN]                 may be null
     T2* y;        // [MN] projection      may be null
     double* sse_part;   // [numTiles]
-    int nostore;        // experiment: compute the block but skip its stores unless a value is NaN
 };
 
 template <int MODEL, typename T>
@@ -152,20 +151,11 @@ __global__ __launch_bounds__(kTile) void jacobian_kernel(JacArgs<T> a) {
         const T* vc = svc + (a.pt_view[p] - v0) * kViewStride;
         T u, v;
         if (a.J) {
-            T Ju[C], Jv[C];
-            jacobian_point<MODEL, T>(sp, vc, xy.x, xy.y, z, u, v, Ju, Jv);
+            T2 Jc[C];
+            jacobian_point<MODEL, T>(sp, vc, xy.x, xy.y, z, u, v, Jc);
             T2* dst = a.J + jIndex(p - a.p_begin, 0, C);
-            bool store = true;
-            if (a.nostore) {
-                T acc = T(0);
 #pragma unroll
-                for (int c = 0; c < C; ++c) acc += Ju[c] + Jv[c];
-                store = acc != acc;      // never true for finite data; keeps the arithmetic live
-            }
-            if (store) {
-#pragma unroll
-                for (int c = 0; c < C; ++c) { T2 t; t.x = Ju[c]; t.y = Jv[c]; dst[4 * c] = t; }
-            }
+            for (int c = 0; c < C; ++c) dst[4 * c] = Jc[c];
         } else {
             project_point<MODEL, T>(sp, vc, xy.x, xy.y, z, u, v);
         }
@@ -344,8 +334,9 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
                 pn = pbeg + (q + 64 < qend ? q + 64 : qend - 1);
                 m_n = uv[pn]; xy_n = XY[pn]; z_n = Z[pn];
             }
-            T u, v, Ju[C], Jv[C];
-            jacobian_point<MODEL, T>(sp, vc, xy.x, xy.y, z, u, v, Ju, Jv);
+            T u, v;
+            T2 Jc[C];
+            jacobian_point<MODEL, T>(sp, vc, xy.x, xy.y, z, u, v, Jc);
             T2 res;
             res.x = pvalid ? m.x - u : T(0);
             res.y = pvalid ? m.y - v : T(0);
@@ -358,8 +349,8 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
 #pragma unroll
                     for (int cc = 0; cc < C; ++cc) {
                         T2 t;
-                        t.x = pvalid ? Ju[cc] : T(0);
-                        t.y = pvalid ? Jv[cc] : T(0);
+                        t.x = pvalid ? Jc[cc].x : T(0);
+                        t.y = pvalid ? Jc[cc].y : T(0);
                         row[cc] = t;
                     }
                     if (C < 16) { T2 t; t.x = T(0); t.y = T(0); row[15] = t; }

@@ -113,13 +113,13 @@ __device__ __forceinline__ void project_point(const Shared<MODEL, T>& sp, const 
     v = sp.be * yd + sp.vc;
 }
 
-// Projection + the point's 2 x C Jacobian block. Ju/Jv column order is the
-// reference's (src/jacobian.py:22-26): [alpha beta gamma uc vc | k.. | rx ry rz tx ty tz].
+// Projection + the point's 2 x C Jacobian block, J[c] = (du/dp_c, dv/dp_c) (one 16-byte pair per
+// column: what the HBM layout and the LDS transpose move). Column order is the reference's
+// (src/jacobian.py:22-26): [alpha beta gamma uc vc | k.. | rx ry rz tx ty tz].
 template <int MODEL, typename T>
 __device__ __forceinline__ void jacobian_point(const Shared<MODEL, T>& sp, const T* __restrict__ vc,
                                                T X, T Y, T Z, T& u, T& v,
-                                               T (&Ju)[ModelTraits<MODEL>::C],
-                                               T (&Jv)[ModelTraits<MODEL>::C]) {
+                                               typename Pair<T>::type (&J)[ModelTraits<MODEL>::C]) {
     constexpr int NK = ModelTraits<MODEL>::NK;
     constexpr int L = ModelTraits<MODEL>::L;
     const T q0 = vc[0] * X + vc[1] * Y + vc[2] * Z;
@@ -137,15 +137,15 @@ __device__ __forceinline__ void jacobian_point(const Shared<MODEL, T>& sp, const
     u = sp.al * xd + sp.ga * yd + sp.uc;
     v = sp.be * yd + sp.vc;
 
-    Ju[0] = xd;   Jv[0] = T(0);
-    Ju[1] = T(0); Jv[1] = yd;
-    Ju[2] = yd;   Jv[2] = T(0);
-    Ju[3] = T(1); Jv[3] = T(0);
-    Ju[4] = T(0); Jv[4] = T(1);
+    J[0].x = xd;   J[0].y = T(0);
+    J[1].x = T(0); J[1].y = yd;
+    J[2].x = yd;   J[2].y = T(0);
+    J[3].x = T(1); J[3].y = T(0);
+    J[4].x = T(0); J[4].y = T(1);
 #pragma unroll
     for (int j = 0; j < NK; ++j) {
-        Ju[5 + j] = sp.al * dkx[j] + sp.ga * dky[j];
-        Jv[5 + j] = sp.be * dky[j];
+        J[5 + j].x = sp.al * dkx[j] + sp.ga * dky[j];
+        J[5 + j].y = sp.be * dky[j];
     }
     // d(u,v)/d(x,y), pre-scaled by 1/Zc
     const T ux = (sp.al * xd_x + sp.ga * yd_x) * iz;
@@ -159,18 +159,18 @@ __device__ __forceinline__ void jacobian_point(const Shared<MODEL, T>& sp, const
     // rho_x
     dX = ax1 * q2 - ax2 * q1;  dY = ax2 * q0 - ax0 * q2;  dZ = ax0 * q1 - ax1 * q0;
     dx = dX - x * dZ;  dy = dY - y * dZ;
-    Ju[L + 0] = ux * dx + uy * dy;  Jv[L + 0] = vx * dx + vy * dy;
+    J[L + 0].x = ux * dx + uy * dy;  J[L + 0].y = vx * dx + vy * dy;
     // rho_y  (a_y.z = 0)
     dX = ay1 * q2;  dY = -ay0 * q2;  dZ = ay0 * q1 - ay1 * q0;
     dx = dX - x * dZ;  dy = dY - y * dZ;
-    Ju[L + 1] = ux * dx + uy * dy;  Jv[L + 1] = vx * dx + vy * dy;
+    J[L + 1].x = ux * dx + uy * dy;  J[L + 1].y = vx * dx + vy * dy;
     // rho_z  (e_z x q = (-q1, q0, 0))
     dx = -deg * q1;  dy = deg * q0;
-    Ju[L + 2] = ux * dx + uy * dy;  Jv[L + 2] = vx * dx + vy * dy;
+    J[L + 2].x = ux * dx + uy * dy;  J[L + 2].y = vx * dx + vy * dy;
     // t
-    Ju[L + 3] = ux;  Jv[L + 3] = vx;
-    Ju[L + 4] = uy;  Jv[L + 4] = vy;
-    Ju[L + 5] = -(ux * x + uy * y);  Jv[L + 5] = -(vx * x + vy * y);
+    J[L + 3].x = ux;  J[L + 3].y = vx;
+    J[L + 4].x = uy;  J[L + 4].y = vy;
+    J[L + 5].x = -(ux * x + uy * y);  J[L + 5].y = -(vx * x + vy * y);
 }
 
 }  // namespace calib
