@@ -81,6 +81,12 @@ def main():
     ap.add_argument("--noise", type=float, default=0.1, help="sensor noise sigma in px")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lm-mode", default="fused", choices=["fused", "two_kernel"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
+                         "multi-rank path with several ranks on one GPU)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: drive the sharded (all-reduce per round) path even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -95,11 +101,21 @@ def main():
     import camera_calibration_amd as cca
     from camera_calibration_amd import distributed, synthetic
 
+    if args.same_device:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
 
     cfg = dict(synthetic.CONFIGS[args.workload])
     viewsPerGpu = args.views or cfg["views"]
@@ -127,7 +143,7 @@ def main():
         torch.cuda.synchronize()
         eng.lmDone()        # synchronises the engine's stream (its own stream when N == 1)
 
-    if world > 1:
+    if dist is not None:
         allReduce = distributed.torchAllReduce(eng, torch.device("cuda", local))
         lm = distributed.ShardedLM(eng, allReduce)
         lm.begin(shard["P0"], total, **lmOpts)

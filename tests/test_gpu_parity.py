@@ -259,3 +259,19 @@ def test_fused_and_two_kernel_modes_agree(tag, name):
     assert np.array_equal(a[8][:n, 3], b[8][:n, 3])
     assert np.abs(a[6][:10] - b[6][:10]).max() < 1e-9
     assert np.abs(a[6][:10] - g["Pfinal"][:10]).max() < 1e-9
+
+
+def test_end_to_end_calibrate_matches_reference(capsys):
+    # tests/itest_main.py:12-29 through the facade: host DLT initialisation + device refinement
+    g = loadGolden("g4_realistic.npz")
+    offs = g["viewOffsets"]
+    dets = [(g["sensorPoints"][a:b], g["modelPoints"][a:b]) for a, b in zip(offs[:-1], offs[1:])]
+    sse, A, W, k = cca.calibrateCamera(dets, "radtan", 100)
+    assert sse == pytest.approx(0, abs=1e-7)
+    assert np.allclose(A, g["Atrue"], atol=1e-9) and np.allclose(k, g["ktrue"], atol=1e-9)
+    for we, wc in zip(g["Wtrue"], W):
+        assert np.allclose(we, wc, atol=1e-6)
+    out = capsys.readouterr().out
+    assert "iter 0:" in out and "λ=1.000000e-03" in out and "A:" in out       # src/calibrate.py:269-274
+    with pytest.raises(ValueError):
+        cca.calibrateCamera(dets, "pinhole", 1)

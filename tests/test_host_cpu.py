@@ -81,3 +81,26 @@ def test_synthetic_pose_sampler_vs_reference_dataset():
         # any sub-range gives the same poses (global view index)
         W2 = synthetic.sampleBoardPosesInCamera(corners, np.arange(5, 9))
         assert np.array_equal(W2, W[5:9])
+
+
+@pytest.mark.parametrize("tag,name", [("g2_config1_radtan.npz", "radtan"), ("g2_config1_fisheye.npz", "fisheye"),
+                                      ("g3_unittest15.npz", "radtan"), ("g4_realistic.npz", "radtan")])
+def test_linear_initialisation_vs_reference(tag, name):
+    """Host closed-form stage (batched numpy) against what the reference's
+    estimateCalibrationParameters produced on the same detections (src/calibrate.py:41-58)."""
+    from camera_calibration_amd import linearcalibrate as lc
+    g = loadGolden(tag)
+    offs = g["viewOffsets"]
+    dets = [(g["sensorPoints"][a:b], g["modelPoints"][a:b]) for a, b in zip(offs[:-1], offs[1:])]
+    model = cca.RadialTangentialModel() if name == "radtan" else cca.FisheyeModel()
+    A, W, k = lc.estimateCalibrationParameters(model, dets)
+    assert A.shape == (3, 3) and len(W) == len(dets) and len(k) == len(model.getDistortionSymbols())
+    assert np.abs(A - g["A0"]).max() < 1e-5           # tests/test_linearcalibrate.py holds A to 1e-6 relative
+    assert np.abs(np.array(W) - g["W0"]).max() < 1e-6
+    assert np.abs(np.array(k) - g["k0"]).max() < 1e-5
+    # homographies reproject the detections (tests/test_linearcalibrate.py:55-75, 1e-3 bar is on H itself)
+    Hs = lc.refineHomographies(lc.estimateHomographies(dets), dets)
+    for H, (s, m) in zip(Hs[:3], dets[:3]):
+        p = np.column_stack((m[:, :2], np.ones(m.shape[0]))) @ H.T
+        assert np.abs(p[:, :2] / p[:, 2:3] - s).max() < 30.0      # lens distortion is not in H
+    assert abs(Hs[0][2, 2] - 1.0) < 1e-15
