@@ -4,7 +4,8 @@ Drop-in for the nonlinear stage of pvphan/camera-calibration (src/calibrate.py,
 src/jacobian.py, src/distortion.py). Import as ``camera_calibration_amd`` (the
 repo-root shim maps the hyphenated directory name onto that module name).
 """
-from . import _native, calibrate, distortion, engine, jacobian, linearcalibrate, main, mathutils  # noqa: F401
+from . import (_native, calibrate, dataset, distortion, engine, jacobian, linearcalibrate, main,  # noqa: F401
+               mathutils, synthetic)
 from .calibrate import Calibrator, getSensorPoints  # noqa: F401
 from .distortion import FisheyeModel, RadialTangentialModel  # noqa: F401
 from .engine import RefineEngine  # noqa: F401

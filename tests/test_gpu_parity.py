@@ -275,3 +275,36 @@ def test_end_to_end_calibrate_matches_reference(capsys):
     assert "iter 0:" in out and "λ=1.000000e-03" in out and "A:" in out       # src/calibrate.py:269-274
     with pytest.raises(ValueError):
         cca.calibrateCamera(dets, "pinhole", 1)
+
+
+def test_dataset_generator_reproduces_reference_datasets():
+    """Dataset (host pose sampling + device projection + image crop) against the detections the
+    reference generated: the ragged 15-view unit-test dataset and the cropped bench boards."""
+    from camera_calibration_amd import dataset
+    g = loadGolden("g3_unittest15.npz")
+    ds = dataset.createSyntheticDatasetRadTan(g["Atrue"], 640, 480, tuple(g["ktrue"]), None)
+    dets = ds.getCornerDetectionsInSensorCoordinates()
+    offs = np.concatenate(([0], np.cumsum([s.shape[0] for s, m in dets])))
+    assert np.array_equal(offs, g["viewOffsets"])                       # same crop decisions
+    assert np.abs(np.vstack([s for s, m in dets]) - g["sensorPoints"]).max() < 1e-9
+    assert np.array_equal(np.vstack([m for s, m in dets]), g["modelPoints"])
+    assert np.abs(np.array(ds.getAllBoardPosesInCamera()) - g["Wtrue"]).max() < 1e-13
+    g6 = loadGolden("g6_generator.npz")
+    for tag in ("c2", "c3", "c5"):
+        cfg = synthetic.CONFIGS[tag]
+        model = cca.RadialTangentialModel() if cfg["model"] == "radtan" else cca.FisheyeModel()
+        w, h = g6[f"{tag}_wh"]
+        cam = dataset.VirtualCamera(g6[f"{tag}_A"], tuple(g6[f"{tag}_k"]), model, int(w), int(h), None)
+        board = dataset.Checkerboard(*cfg["board"])
+        d = dataset.Dataset(board, cam, 12)
+        dets = d.getCornerDetectionsInSensorCoordinates()
+        offs = np.concatenate(([0], np.cumsum([s.shape[0] for s, m in dets])))
+        # the reference drops a fisheye point exactly on the optical axis (0/0 -> NaN fails its crop
+        # test); the engine returns the limit (uc, vc) for it, so a view may keep one point more
+        ref = g6[f"{tag}_cropOffsets"]
+        assert np.all(np.diff(offs) - np.diff(ref) >= 0) and np.all(np.diff(offs) - np.diff(ref) <= 1)
+        full = dataset.Dataset(board, cam, 12, crop=False).getCornerDetectionsInSensorCoordinates()
+        yfull = np.array([s for s, m in full])
+        refy = g6[f"{tag}_yfull"]
+        ok = ~np.isnan(refy)
+        assert np.abs(yfull[ok] - refy[ok]).max() < 1e-9

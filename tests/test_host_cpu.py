@@ -104,3 +104,20 @@ def test_linear_initialisation_vs_reference(tag, name):
         p = np.column_stack((m[:, :2], np.ones(m.shape[0]))) @ H.T
         assert np.abs(p[:, :2] / p[:, 2:3] - s).max() < 30.0      # lens distortion is not in H
     assert abs(Hs[0][2, 2] - 1.0) < 1e-15
+
+
+def test_detections_json_roundtrip(tmp_path):
+    # tests/test_dataset.py:70-90: exportDetections / createDetectionsFromPath, same JSON schema
+    from camera_calibration_amd import dataset
+    g = loadGolden("g3_unittest15.npz")
+    offs = g["viewOffsets"]
+    dets = [(g["sensorPoints"][a:b], g["modelPoints"][a:b]) for a, b in zip(offs[:-1], offs[1:])]
+    path = str(tmp_path / "detections.json")
+    dataset.exportDetections(dets, path)
+    import json
+    doc = json.load(open(path))
+    assert set(doc) == {"views"} and set(doc["views"][0]) == {"sensorPoints", "modelPoints"}
+    back = dataset.createDetectionsFromPath(path)
+    assert len(back) == len(dets)
+    for (s0, m0), (s1, m1) in zip(dets, back):
+        assert np.array_equal(s0, s1) and np.array_equal(m0, m1)
