@@ -337,9 +337,12 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
             T u, v;
             T2 Jc[C];
             jacobian_point<MODEL, T>(sp, vc, xy.x, xy.y, z, u, v, Jc);
+            // lanes past the item's end evaluate a clamped (finite) point; their rows are only ever
+            // read as part of the last, partial 4-point group, where they are zeroed at the read
+            (void)pvalid;
             T2 res;
-            res.x = pvalid ? m.x - u : T(0);
-            res.y = pvalid ? m.y - v : T(0);
+            res.x = m.x - u;
+            res.y = m.y - v;
 #pragma unroll
             for (int half = 0; half < HALVES; ++half) {
                 if (q0 + ROWS * half >= qend) break;            // wave-uniform
@@ -347,12 +350,7 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
                 if (HALVES == 1 || (lane >> 5) == half) {
                     T2* row = slab + (lane & (ROWS - 1)) * RS;
 #pragma unroll
-                    for (int cc = 0; cc < C; ++cc) {
-                        T2 t;
-                        t.x = pvalid ? Jc[cc].x : T(0);
-                        t.y = pvalid ? Jc[cc].y : T(0);
-                        row[cc] = t;
-                    }
+                    for (int cc = 0; cc < C; ++cc) row[cc] = Jc[cc];
                     if (C < 16) { T2 t; t.x = T(0); t.y = T(0); row[15] = t; }
                     rslab[lane & (ROWS - 1)] = res;
                 }
@@ -363,8 +361,11 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
                     if (4 * s >= rows) break;                   // wave-uniform
                     const T2 jv = slab[(4 * s + k) * RS + c];
                     const T2 rv = rslab[4 * s + k];
-                    const double jx = (double)jv.x, jy = (double)jv.y;
-                    const double rx = (double)rv.x, ry = (double)rv.y;
+                    double jx = (double)jv.x, jy = (double)jv.y;
+                    double rx = (double)rv.x, ry = (double)rv.y;
+                    if (4 * s + 4 > rows && 4 * s + k >= rows) {        // partial last group (outer test wave-uniform)
+                        jx = 0.0; jy = 0.0; rx = 0.0; ry = 0.0;
+                    }
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jx, jx, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc, 0, 0, 0);
                     gacc += jx * rx + jy * ry;
