@@ -61,6 +61,26 @@ def cpuBaseline(shard, cfgName, seconds=20.0):
         threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
         threads = os.cpu_count()
+    cPort = None
+    try:
+        from oracle import c_oracle
+        if c_oracle.available():
+            # the C/OpenMP restatement (block-arrow / Schur form) on ALL host cores, on the whole shard
+            full = (shard["viewOffsets"], shard["sensorPoints"], shard["modelPoints"])
+            t0 = time.perf_counter()
+            c_oracle.refine(model, shard["P0"], *full, 1, lamMin=0.0, lamMax=np.inf, errMin=-np.inf)
+            t1 = time.perf_counter() - t0
+            citers = int(max(2, min(20, seconds / max(t1, 1e-3))))
+            t0 = time.perf_counter()
+            c_oracle.refine(model, shard["P0"], *full, citers, lamMin=0.0, lamMax=np.inf, errMin=-np.inf)
+            tC = time.perf_counter() - t0
+            cPort = {"value": int(full[0][-1]) * citers / tC, "unit": "point-residuals/s",
+                     "cores": os.cpu_count(), "kind": "port",
+                     "sample": f"whole {cfgName} shard ({int(full[0][-1])} points), {citers} LM iterations of "
+                               f"oracle/calib_oracle.c (Schur form, OpenMP over views, {os.cpu_count()} "
+                               f"hardware threads), {tC:.1f} s"}
+    except Exception as e:       # the C oracle is optional test infrastructure
+        cPort = {"error": str(e)}
     return {
         "value": n * iters / tDense, "unit": "point-residuals/s", "cores": int(threads), "kind": "port",
         "sample": f"first {views} views x {N} pts of {cfgName} ({n} points), {iters} LM iterations of "
@@ -68,6 +88,7 @@ def cpuBaseline(shard, cfgName, seconds=20.0):
                   f"(oracle.refineDense), {tDense:.1f} s; BLAS uses {threads} threads, the rest is 1 thread",
         "schur_form_value": n * iters / tSchur,
         "schur_form_note": f"same sample through the block-arrow/Schur numpy oracle, {tSchur:.2f} s",
+        "c_openmp_port": cPort,
     }
 
 

@@ -140,3 +140,44 @@ def test_g6_generator_poses():
         assert np.array_equal(corners, g[f"{tag}_corners"])
         W = orc.syntheticBoardPoses(corners, range(12))
         assert np.abs(W - g[f"{tag}_W"]).max() < 1e-14
+
+
+@pytest.fixture(scope="module")
+def corc():
+    """oracle/calib_oracle.c (gcc + OpenMP), built on demand"""
+    import subprocess
+    from conftest import ROOT
+    import os
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+    from oracle import c_oracle
+    return c_oracle
+
+
+@pytest.mark.parametrize("name,model", MODELS)
+def test_c_oracle_matches_reference_vectors(corc, name, model):
+    g = loadGolden(f"g2_config1_{name}.npz")
+    offs, s, m, P0 = g["viewOffsets"], g["sensorPoints"], g["modelPoints"], g["P0"]
+    L = orc.numShared(model)
+    ev = corc.evaluate(model, P0, offs, s, m, wantJ=True)
+    assert np.abs(ev["y"] - g["y0"]).max() < 1e-11
+    assert abs(ev["sse"] - g["err0"]) < 1e-11 * g["err0"]
+    Jd = g["J"]                                           # the reference's dense J
+    n = ev["Jc"].shape[0]
+    assert np.abs(ev["Jc"][:, :, :L].reshape(2 * n, L) - Jd[:, :L]).max() / np.abs(Jd).max() < 1e-14
+    d = corc.step(model, P0, offs, s, m, 1e-3)
+    assert np.linalg.norm(d - g["delta"]) / np.linalg.norm(g["delta"]) < 1e-8
+    sse, P, trace = corc.refine(model, P0, offs, s, m, int(g["maxIters"]))
+    ref = g["traceIterErrLam"]
+    assert trace.shape[0] == ref.shape[0] and np.array_equal(trace[:, 3], ref[:, 2])
+    assert np.abs(P[:L] - g["Pfinal"][:L]).max() < 1e-9
+
+
+def test_c_oracle_ragged_and_realistic(corc):
+    for tag in ("g3_unittest15.npz", "g4_realistic.npz", "g5_ragged200.npz"):
+        g = loadGolden(tag)
+        offs, s, m, P0 = g["viewOffsets"], g["sensorPoints"], g["modelPoints"], g["P0"]
+        d = corc.step(orc.RADTAN, P0, offs, s, m, 1e-3)
+        assert np.linalg.norm(d - g["delta"]) / np.linalg.norm(g["delta"]) < 1e-8
+        sse, P, trace = corc.refine(orc.RADTAN, P0, offs, s, m, 100)
+        target = g["Pfinal"][:10] if "Pfinal" in g.files else g["Ptrue"][:10]
+        assert sse < 1e-7 and np.abs(P[:10] - target).max() < 1e-9
