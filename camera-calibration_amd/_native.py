@@ -52,6 +52,8 @@ SIGNATURES = {
     "calib_distort_points": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p]),
     "calib_project_with_distortion": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, _c_double_p, _c_double_p,
                                                      _c_double_p, _c_double_p]),
+    "calib_refine_homographies": (ctypes.c_int, [ctypes.c_int64, _c_int64_p, _c_double_p, _c_double_p, _c_double_p,
+                                                 ctypes.c_int, ctypes.c_int]),
     "calib_profile_enable": (ctypes.c_int, [_h, ctypes.c_int]),
     "calib_profile_read": (ctypes.c_int, [_h, ctypes.c_int, _c_double_p, _c_int64_p]),
 }

@@ -40,7 +40,13 @@ class Calibrator:
     def estimateCalibrationParameters(self, allDetections):
         """src/calibrate.py:41-58: Zhang's closed-form initialisation, on the host."""
         from . import linearcalibrate
-        return linearcalibrate.estimateCalibrationParameters(self._distortionModel, allDetections)
+        return linearcalibrate.estimateCalibrationParameters(self._distortionModel, allDetections,
+                                                             refine=self._refineHomographies)
+
+    def _refineHomographies(self, Hs, allDetections):
+        """LM polish of the DLT homographies, all views in one device launch (src/calibrate.py:60-67)"""
+        offs, sensor, model = engine.packDetections(allDetections)
+        return list(engine.refineHomographies(Hs, offs, sensor, model, 20, self._device))
 
     # ---- the hot path --------------------------------------------------------------------
     def refineCalibrationParameters(self, Ainitial, Winitial, kInitial, allDetections,

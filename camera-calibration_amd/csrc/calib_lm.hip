@@ -810,6 +810,44 @@ int calib_project_with_distortion(int model, int64_t n, const double* A, const d
     return CALIB_OK;
 }
 
+int calib_refine_homographies(int64_t num_views, const int64_t* view_offsets, const double* sensor_uv,
+                              const double* model_xyz, double* H_inout, int max_iters, int device_id) {
+    if (num_views < 0 || !view_offsets || !H_inout) return fail(CALIB_E_INVALID, "null argument");
+    if (num_views == 0) return CALIB_OK;
+    const int64_t MN = view_offsets[num_views];
+    if (view_offsets[0] != 0 || MN < 0 || (MN > 0 && (!sensor_uv || !model_xyz)))
+        return fail(CALIB_E_INVALID, "bad view_offsets / point arrays");
+    for (int64_t i = 0; i < num_views; ++i)
+        if (view_offsets[i + 1] < view_offsets[i]) return fail(CALIB_E_INVALID, "view_offsets must be non-decreasing");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(CALIB_E_HIP, "no such HIP device (no CPU fallback)");
+    HIP_TRY(hipSetDevice(device_id));
+    std::vector<double> xy((size_t)MN * 2);
+    for (int64_t p = 0; p < MN; ++p) { xy[2 * p] = model_xyz[3 * p]; xy[2 * p + 1] = model_xyz[3 * p + 1]; }
+    DevBuf<int64_t> doffs;
+    DevBuf<double> duv, dxy, dH;
+    hipError_t e = doffs.alloc((size_t)num_views + 1);
+    if (e == hipSuccess) e = duv.alloc((size_t)std::max<int64_t>(MN, 1) * 2);
+    if (e == hipSuccess) e = dxy.alloc((size_t)std::max<int64_t>(MN, 1) * 2);
+    if (e == hipSuccess) e = dH.alloc((size_t)num_views * 9);
+    if (e == hipSuccess) e = hipMemcpy(doffs.p, view_offsets, ((size_t)num_views + 1) * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && MN) e = hipMemcpy(duv.p, sensor_uv, (size_t)MN * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess && MN) e = hipMemcpy(dxy.p, xy.data(), (size_t)MN * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dH.p, H_inout, (size_t)num_views * 72, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const unsigned blocks = (unsigned)((num_views + 15) / 16);
+        hipLaunchKernelGGL(homography_lm_kernel, dim3(blocks), dim3(256), 0, 0, doffs.p,
+                           reinterpret_cast<const double2*>(duv.p), reinterpret_cast<const double2*>(dxy.p),
+                           num_views, max_iters, dH.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(H_inout, dH.p, (size_t)num_views * 72, hipMemcpyDeviceToHost);
+    doffs.release(); duv.release(); dxy.release(); dH.release();
+    if (e != hipSuccess) return fail(CALIB_E_HIP, hipGetErrorString(e));
+    return CALIB_OK;
+}
+
 int calib_profile_enable(calib_handle_t h, int on) {
     CHECK_H(h);
     HIP_TRY(hipStreamSynchronize(h->stream));

@@ -646,6 +646,45 @@ __global__ __launch_bounds__(256) void sse_reduce_kernel(const double* __restric
     if (tid == 0) out[0] = ssum[0];
 }
 
+// ---------------------------------------------------------------- N x N solve on 16 lanes
+// Gauss-Jordan with partial pivoting; lane i < N owns row i of [S | s] (row[N] = rhs), lanes >= N
+// hold zero rows. On return the lane that served as pivot row for column myCol holds x[myCol] in d
+// (myCol = -1 on the other lanes). Returns true when a pivot is exactly zero / not finite.
+template <int N>
+__device__ __forceinline__ bool gauss_jordan16(double (&row)[N + 1], int i, int& myCol, double& d) {
+    bool used = false, singular = false;
+    myCol = -1;
+#pragma unroll
+    for (int col = 0; col < N; ++col) {
+        double best = (!used && i < N) ? fabs(row[col]) : -1.0;
+        int bi = i;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            const double ob = __shfl_xor(best, off, 16);
+            const int oi = __shfl_xor(bi, off, 16);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (!(best > 0.0)) singular = true;
+        double prow[N + 1];
+#pragma unroll
+        for (int j = col; j <= N; ++j) prow[j] = __shfl(row[j], bi, 16);
+        if (i == bi) {
+            used = true;
+            myCol = col;
+        } else {
+            const double f = row[col] / prow[col];
+#pragma unroll
+            for (int j = col + 1; j <= N; ++j) row[j] -= f * prow[j];
+            row[col] = 0.0;
+        }
+    }
+    double piv = 1.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) if (myCol == j) piv = row[j];
+    d = row[N] / piv;
+    return singular;
+}
+
 // ---------------------------------------------------------------- update (16 lanes)
 // The control flow of src/calibrate.py:155-168 on the device, then the L x L solve
 // (J^T J + lam diag)^-1 restricted to the shared block: S dc = s. Lane i owns row i of [S | s];
@@ -720,38 +759,10 @@ __global__ __launch_bounds__(64) void update_kernel(LMState* __restrict__ st, co
             st->gc[i] = gci;
         }
     }
-    bool used = false, singular = false;
-    int myCol = -1;
-#pragma unroll
-    for (int col = 0; col < L; ++col) {
-        double best = (!used && i < L) ? fabs(row[col]) : -1.0;
-        int bi = i;
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {
-            const double ob = __shfl_xor(best, off, 16);
-            const int oi = __shfl_xor(bi, off, 16);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-        }
-        if (!(best > 0.0)) singular = true;
-        double prow[L + 1];
-#pragma unroll
-        for (int j = col; j <= L; ++j) prow[j] = __shfl(row[j], bi, 16);
-        if (i == bi) {
-            used = true;
-            myCol = col;
-        } else {
-            const double f = row[col] / prow[col];
-#pragma unroll
-            for (int j = col + 1; j <= L; ++j) row[j] -= f * prow[j];
-            row[col] = 0.0;
-        }
-    }
-    if (singular) { if (lane == 0) { st->error = -3; st->done = 1; } return; }
-    double piv = 1.0;
-#pragma unroll
-    for (int j = 0; j < L; ++j) if (myCol == j) piv = row[j];
+    int myCol;
+    double d;
+    if (gauss_jordan16<L>(row, i, myCol, d)) { if (lane == 0) { st->error = -3; st->done = 1; } return; }
     if (writer && myCol >= 0) {
-        const double d = row[L] / piv;
         st->dc[myCol] = d;
         Pb[cur ^ 1][myCol] = Pb[cur][myCol] + d;
     }
@@ -807,6 +818,113 @@ __global__ __launch_bounds__(kSchurThreads) void backsub_kernel(const double* __
         for (int m = 1; m < 6; ++m) dv = (c == m) ? d[m] : dv;
         Pn[o] = Pc[o] + dv;
     }
+}
+
+// ---------------------------------------------------------------- per-view homography LM
+// Calibrator._refineHomography (src/calibrate.py:69-111) for every view at once: 16 lanes per
+// view run the whole 20-iteration loop (lambda 1e-3, /10 on an accepted step, x10 otherwise,
+// stop when lambda leaves (1e-10, 1e10) or the error drops below 1e-12), then H /= H[2,2].
+// With p = (X, Y, 1)/w, the 9-column Jacobian rows of HomographyJacobian (src/jacobian.py:88-121)
+// are Ju = (p, 0, -u p), Jv = (0, p, -v p), so J^T J = [[A,0,-uA],[0,A,-vA],[.,.,(u^2+v^2)A]] with
+// A = p p^T: 24 sums + 9 gradient sums + the error per pass, reduced across the 16 lanes.
+__device__ __forceinline__ double group_sum16(double v) {
+    v += __shfl_xor(v, 1, 16);
+    v += __shfl_xor(v, 2, 16);
+    v += __shfl_xor(v, 4, 16);
+    v += __shfl_xor(v, 8, 16);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void homography_lm_kernel(const int64_t* __restrict__ offs,
+                                                            const double2* __restrict__ uv,
+                                                            const double2* __restrict__ XY, int64_t M,
+                                                            int max_iters, double* __restrict__ H) {
+    const int tid = threadIdx.x, i = tid & 15;
+    const int64_t view = (int64_t)blockIdx.x * 16 + (tid >> 4);
+    if (view >= M) return;                     // whole 16-lane group together
+    const int64_t p0 = offs[view];
+    const int n = (int)(offs[view + 1] - p0);
+    double h[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) h[j] = H[view * 9 + j];
+    double lam = 1e-3;
+    bool active = n > 0;
+    for (int it = 0; it < max_iters && active; ++it) {
+        double SA[6] = {0, 0, 0, 0, 0, 0}, SU[6] = {0, 0, 0, 0, 0, 0}, SV[6] = {0, 0, 0, 0, 0, 0},
+               SE[6] = {0, 0, 0, 0, 0, 0}, g[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, err0 = 0.0;
+        for (int q = i; q < n; q += 16) {
+            const double2 m = uv[p0 + q], xy = XY[p0 + q];
+            const double iw = 1.0 / (h[6] * xy.x + h[7] * xy.y + h[8]);
+            const double u = (h[0] * xy.x + h[1] * xy.y + h[2]) * iw;
+            const double v = (h[3] * xy.x + h[4] * xy.y + h[5]) * iw;
+            const double px = xy.x * iw, py = xy.y * iw, pz = iw;
+            const double a[6] = {px * px, px * py, px * pz, py * py, py * pz, pz * pz};
+            const double ru = m.x - u, rv = m.y - v, e2 = u * u + v * v, rw = -(u * ru + v * rv);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) { SA[j] += a[j]; SU[j] += u * a[j]; SV[j] += v * a[j]; SE[j] += e2 * a[j]; }
+            g[0] += ru * px; g[1] += ru * py; g[2] += ru * pz;
+            g[3] += rv * px; g[4] += rv * py; g[5] += rv * pz;
+            g[6] += rw * px; g[7] += rw * py; g[8] += rw * pz;
+            err0 += ru * ru + rv * rv;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { SA[j] = group_sum16(SA[j]); SU[j] = group_sum16(SU[j]); SV[j] = group_sum16(SV[j]); SE[j] = group_sum16(SE[j]); }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) g[j] = group_sum16(g[j]);
+        err0 = group_sum16(err0);
+        // row i of J^T J + lam diag(J^T J) | J^T r; symmetric 3x3 blocks indexed (0,0)(0,1)(0,2)(1,1)(1,2)(2,2)
+        auto sym = [](const double (&S)[6], int r, int c) { const int lo = r < c ? r : c, hi = r < c ? c : r;
+                                                           return S[lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)]; };
+        double row[10];
+#pragma unroll
+        for (int j = 0; j <= 9; ++j) row[j] = 0.0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            if (i == r) {
+                const int br = r / 3, rr = r % 3;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) {
+                    const int bc = c / 3, cc = c % 3;
+                    double t = 0.0;
+                    if (br == bc) t = br == 2 ? sym(SE, rr, cc) : sym(SA, rr, cc);
+                    else if (br + bc == 2 && br != bc) t = -sym(SU, rr, cc);          // blocks (0,2),(2,0)
+                    else if (br + bc == 3) t = -sym(SV, rr, cc);                       // blocks (1,2),(2,1)
+                    row[c] = t;
+                }
+                row[9] = g[r];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) if (i == c) row[c] += lam * row[c];
+        int myCol;
+        double d;
+        const bool singular = gauss_jordan16<9>(row, i, myCol, d);
+        double delta[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) delta[c] = group_sum16(myCol == c ? d : 0.0);
+        double h1[9], err1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) h1[j] = h[j] + delta[j];
+        for (int q = i; q < n; q += 16) {
+            const double2 m = uv[p0 + q], xy = XY[p0 + q];
+            const double iw = 1.0 / (h1[6] * xy.x + h1[7] * xy.y + h1[8]);
+            const double ru = m.x - (h1[0] * xy.x + h1[1] * xy.y + h1[2]) * iw;
+            const double rv = m.y - (h1[3] * xy.x + h1[4] * xy.y + h1[5]) * iw;
+            err1 += ru * ru + rv * rv;
+        }
+        err1 = group_sum16(err1);
+        const bool accept = !singular && err1 < err0;
+        if (accept) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) h[j] = h1[j];
+            lam = lam / 10;
+        } else {
+            lam = lam * 10;
+        }
+        active = (1e-10 < lam && lam < 1e10) && !(err0 < 1e-12) && !singular;
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) if (i == j) H[view * 9 + j] = h[j] / h[8];       // Href /= Href[2,2]
 }
 
 // ---------------------------------------------------------------- small forward-model kernels

@@ -227,6 +227,21 @@ class RefineEngine:
         return ms.value, n.value
 
 
+def refineHomographies(Hs, viewOffsets, sensorPoints, modelPoints, maxIters=20, device=0):
+    """LM polish of every view's homography on the device (src/calibrate.py:60-111).
+    Hs (M,3,3) -> (M,3,3) with H[2,2] = 1."""
+    H = np.ascontiguousarray(np.asarray(Hs, dtype=np.float64).reshape(-1, 3, 3)).copy()
+    offs = np.ascontiguousarray(viewOffsets, dtype=np.int64)
+    s = np.ascontiguousarray(sensorPoints, dtype=np.float64).reshape(-1, 2)
+    m = np.ascontiguousarray(modelPoints, dtype=np.float64).reshape(-1, 3)
+    if offs.shape[0] - 1 != H.shape[0] or s.shape[0] != offs[-1] or m.shape[0] != offs[-1]:
+        raise ValueError(f"Expected {offs.shape[0] - 1} homographies and {int(offs[-1])} points")
+    nat.requireDevice()
+    nat.check(nat.loadLibrary().calib_refine_homographies(H.shape[0], nat.i64ptr(offs), nat.dptr(s), nat.dptr(m),
+                                                          nat.dptr(H), int(maxIters), int(device)))
+    return H
+
+
 def distortPoints(modelId, x, k):
     x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, 2)
     k = np.ascontiguousarray(k, dtype=np.float64).ravel()

@@ -221,10 +221,11 @@ def estimateDistortion(distortionModel, A, allDetections, allBoardPosesInCamera)
     return tuple(k.ravel())
 
 
-def estimateCalibrationParameters(distortionModel, allDetections):
-    """src/calibrate.py:41-58 -> (Ainitial, Winitial, kInitial)"""
+def estimateCalibrationParameters(distortionModel, allDetections, refine=None):
+    """src/calibrate.py:41-58 -> (Ainitial, Winitial, kInitial). `refine(Hs, allDetections)` polishes the
+    homographies (default: the batched host implementation above; Calibrator passes the device kernel)."""
     Hs = estimateHomographies(allDetections)
-    Hsref = refineHomographies(Hs, allDetections)
+    Hsref = (refine or refineHomographies)(Hs, allDetections)
     Ainitial = computeIntrinsicMatrix(Hsref)
     Winitial = computeExtrinsics(Hsref, Ainitial)
     kInitial = estimateDistortion(distortionModel, Ainitial, allDetections, Winitial)

@@ -146,6 +146,13 @@ int calib_distort_points(int model, int64_t n, const double* x_norm, const doubl
 int calib_project_with_distortion(int model, int64_t n, const double* A, const double* cam_xyz,
                                   const double* k, double* out_uv);
 
+/* Per-view homography polish of the initialisation stage: Calibrator._refineHomographies
+ * (src/calibrate.py:60-111, HomographyJacobian src/jacobian.py:88-121), all views in one launch.
+ * H_inout (M,3,3) row-major: DLT homographies in, LM-refined (H[2,2] = 1) out. model_xyz (MN,3):
+ * only X, Y are used. max_iters = 20 in the reference. */
+int calib_refine_homographies(int64_t num_views, const int64_t* view_offsets, const double* sensor_uv,
+                              const double* model_xyz, double* H_inout, int max_iters, int device_id);
+
 /* HIP-event timing of the dominant kernels over the rounds enqueued since the last
  * calib_profile_enable(h, 1). which: 0 = jacobian kernel, 1 = J^T J (MFMA) kernel,
  * 2 = fused jacobian + J^T J kernel. */

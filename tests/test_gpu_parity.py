@@ -308,3 +308,32 @@ def test_dataset_generator_reproduces_reference_datasets():
         refy = g6[f"{tag}_yfull"]
         ok = ~np.isnan(refy)
         assert np.abs(yfull[ok] - refy[ok]).max() < 1e-9
+
+
+def test_homography_lm_on_device_vs_reference():
+    """calib_refine_homographies against the reference's _refineHomographies output (golden g7) and the
+    batched host implementation."""
+    from camera_calibration_amd import engine, linearcalibrate as lc
+    g = loadGolden("g7_homographies.npz")
+    for tag in ("u15", "c1"):
+        offs, s, m = g[f"{tag}_viewOffsets"], g[f"{tag}_sensorPoints"], g[f"{tag}_modelPoints"]
+        H0, Href = g[f"{tag}_H"], g[f"{tag}_Href"]
+        Hd = engine.refineHomographies(H0, offs, s, m)
+        assert Hd.shape == Href.shape and np.all(Hd[:, 2, 2] == 1.0)
+        # the 9-parameter problem has a scale gauge (damped, near-singular solves): compare what is
+        # determined, the normalised homography, at 1e-5 of its scale and through its reprojections
+        assert np.abs(Hd - Href).max() <= 1e-5
+        dets = [(s[a:b], m[a:b]) for a, b in zip(offs[:-1], offs[1:])]
+        Hh = np.array(lc.refineHomographies(list(H0), dets))
+        assert np.abs(Hd - Hh).max() <= 1e-5
+        for H, Hr, (sv, mv) in zip(Hd, Href, dets):
+            p = np.column_stack((mv[:, :2], np.ones(mv.shape[0])))
+            y, yr = p @ H.T, p @ Hr.T
+            assert np.abs(y[:, :2] / y[:, 2:3] - yr[:, :2] / yr[:, 2:3]).max() < 1e-6
+    # the initialisation stage through the Calibrator (device polish) reproduces the reference's P0
+    g3 = loadGolden("g3_unittest15.npz")
+    offs = g3["viewOffsets"]
+    dets = [(g3["sensorPoints"][a:b], g3["modelPoints"][a:b]) for a, b in zip(offs[:-1], offs[1:])]
+    A, W, k = cca.Calibrator(cca.RadialTangentialModel()).estimateCalibrationParameters(dets)
+    assert np.abs(A - g3["A0"]).max() < 1e-5 and np.abs(np.array(W) - g3["W0"]).max() < 1e-6
+    assert np.abs(np.array(k) - g3["k0"]).max() < 1e-5

@@ -17,6 +17,7 @@ G3  the 15-view 25x18 unit-test dataset (ragged views) of tests/test_calibrate.p
 G4  tests/itest_main.py:12-29 realistic radtan calibration (final A, k)
 G5  200 ragged views x <=54 pts: P0, dense delta, Schur inputs
 G6  synthetic-generator poses for the bench boards (src/dataset.py:59-95)
+G7  DLT homographies and their LM polish (src/linearcalibrate.py:7-58, src/calibrate.py:60-115)
 """
 import argparse
 import os
@@ -263,9 +264,30 @@ def g6():
     save("g6_generator.npz", **out)
 
 
+def g7():
+    """Homography stage (src/linearcalibrate.py:7-58, src/calibrate.py:60-115) on the 15-view
+    unit-test dataset and config 1: DLT homographies and their LM-polished versions."""
+    out = {}
+    A = np.array([[400, 0, 320], [0, 400, 240], [0, 0, 1]], dtype=np.float64)
+    k = (-0.5, 0.2, 0.07, -0.03, 0.05)
+    cal = ref.calibrate.Calibrator(ref.distortion.RadialTangentialModel())
+    ds15 = ref.dataset.createSyntheticDatasetRadTan(A, 640, 480, k, None)
+    cam = ref.virtualcamera.VirtualCamera(A, k, ref.distortion.RadialTangentialModel(), 640, 480, None)
+    ds10 = ref.dataset.Dataset(ref.checkerboard.Checkerboard(9, 6, 0.05), cam, 10)
+    for tag, ds in (("u15", ds15), ("c1", ds10)):
+        dets = ds.getCornerDetectionsInSensorCoordinates()
+        offs, sensor, model = packDetections(dets)
+        Hs = ref.linearcalibrate.estimateHomographies(dets)
+        Hdlt = np.array(Hs).copy()          # _refineHomography updates H in place (Pt = H.ravel() is a view)
+        Hsref = cal._refineHomographies(Hs, dets)
+        out.update({f"{tag}_viewOffsets": offs, f"{tag}_sensorPoints": sensor, f"{tag}_modelPoints": model,
+                    f"{tag}_H": Hdlt, f"{tag}_Href": np.array(Hsref)})
+    save("g7_homographies.npz", **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="g0,g1,g2,g3,g4,g5,g6")
+    ap.add_argument("--only", default="g0,g1,g2,g3,g4,g5,g6,g7")
     args = ap.parse_args()
     for g in args.only.split(","):
         t0 = time.time()
