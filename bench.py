@@ -28,6 +28,9 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MATRIX_PEAK_TFLOPS = 78.6  # public MI355X sheet; fp64 MFMA = fp64 vector rate
+# fp64 VALU flops the fused kernel executes per 64-point wave batch (all 64 lanes counted), from
+# rocprofv3 --pmc SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 (profiles/README.md): 64 x (2 FMA + MUL + ADD + TRANS)
+FUSED_VALU_F64_FLOPS_PER_BATCH = {"fisheye": 23.8e3, "radtan": 17.4e3}
 
 
 def algorithmicBytesPerPoint(L, wordBytes):
@@ -70,7 +73,7 @@ def cpuBaseline(shard, cfgName, seconds=20.0):
             t0 = time.perf_counter()
             c_oracle.refine(model, shard["P0"], *full, 1, lamMin=0.0, lamMax=np.inf, errMin=-np.inf)
             t1 = time.perf_counter() - t0
-            citers = int(max(2, min(20, seconds / max(t1, 1e-3))))
+            citers = int(max(2, min(200, seconds / max(t1, 1e-3))))
             t0 = time.perf_counter()
             c_oracle.refine(model, shard["P0"], *full, citers, lamMin=0.0, lamMax=np.inf, errMin=-np.inf)
             tC = time.perf_counter() - t0
@@ -250,11 +253,17 @@ def main():
             fusedAvgMs = fusedMs / fusedN
             fusedPts = MNlocal * args.steps / fusedN
             mfmaFlops = 4 * 16 * 16 * fusedPts               # 2 x v_mfma_f64_16x16x4 (2048 flop) per 4 points
-            tf = mfmaFlops / (fusedAvgMs * 1e-3) / 1e12
+            # fp64 MFMA and fp64 VALU never co-execute on gfx950 (SQ_VALU_MFMA_COEXEC_CYCLES = 0, and
+            # matrix peak = vector peak): both draw on the one 78.6 TFLOP/s fp64 budget
+            batches = viewsPerGpu * (-(-shard["pointsPerView"] // 64)) * args.steps / fusedN
+            valuFlops = (FUSED_VALU_F64_FLOPS_PER_BATCH[cfg["model"]] * batches) if cfg["dtype"] == "f64" else 0.0
+            tf = (mfmaFlops + valuFlops) / (fusedAvgMs * 1e-3) / 1e12
             mainRoof = {"kernel": "fused_kernel (jacobian blocks + v_mfma_f64_16x16x4_f64 J^T J, J on-chip)",
                         "bound": "mfma", "achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": tf / FP64_MATRIX_PEAK_TFLOPS, "traffic": pmc.get("fused_bytes_per_launch"),
-                        "mfma_flops_per_launch": mfmaFlops, "points_per_launch": fusedPts,
+                        "mfma_flops_per_launch": mfmaFlops, "valu_fp64_flops_per_launch": valuFlops,
+                        "mfma_only_frac": mfmaFlops / (fusedAvgMs * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+                        "points_per_launch": fusedPts,
                         "algorithmic_hbm_bytes_per_launch": (5 * w + 4) * fusedPts,
                         "avg_launch_ms": fusedAvgMs, "launches_timed": fusedN}
         else:

@@ -237,29 +237,26 @@ int launch_schur_reduce(calib_handle_s* h, const LMState* st, double* red) {
     return CALIB_OK;
 }
 
-int launch_update_backsub(calib_handle_s* h) {
-    LMState* st = h->st.p;
-    if (h->L == 10)
-        hipLaunchKernelGGL((update_kernel<10>), dim3(1), dim3(64), 0, h->stream, st, h->red, h->P[0].p,
-                           h->P[1].p, h->trace.p);
-    else
-        hipLaunchKernelGGL((update_kernel<9>), dim3(1), dim3(64), 0, h->stream, st, h->red, h->P[0].p,
-                           h->P[1].p, h->trace.p);
+// the LM state is double-buffered per round: kernels of round r read st[r & 1], the update kernel
+// writes st[(r + 1) & 1]
+LMState* st_cur(calib_handle_s* h) { return h->st.p + (h->rounds_enqueued & 1); }
+LMState* st_next(calib_handle_s* h) { return h->st.p + ((h->rounds_enqueued + 1) & 1); }
+
+template <int L, typename T>
+int launch_update_backsub_t(calib_handle_s* h) {
+    const int per = kSchurThreads / 16;
+    const int blocks = std::max(1, (h->nv + per - 1) / per);
+    hipLaunchKernelGGL((update_backsub_kernel<L, T>), dim3(blocks), dim3(kSchurThreads), 0, h->stream, h->G[0].p,
+                       h->G[1].p, st_cur(h), st_next(h), h->red, h->view_item0.p, h->view_ext.p, h->nv,
+                       h->P[0].p, h->P[1].p, h->trace.p, reinterpret_cast<T*>(h->VC.p));
     HIP_TRY(hipGetLastError());
-    if (h->nv > 0) {
-        const int per = kSchurThreads / 16;
-        const int blocks = (h->nv + per - 1) / per;
-        if (h->L == 10)
-            hipLaunchKernelGGL((backsub_kernel<10>), dim3(blocks), dim3(kSchurThreads), 0, h->stream,
-                               h->G[0].p, h->G[1].p, st, h->view_item0.p, h->view_ext.p, h->nv,
-                               h->P[0].p, h->P[1].p);
-        else
-            hipLaunchKernelGGL((backsub_kernel<9>), dim3(blocks), dim3(kSchurThreads), 0, h->stream,
-                               h->G[0].p, h->G[1].p, st, h->view_item0.p, h->view_ext.p, h->nv,
-                               h->P[0].p, h->P[1].p);
-        HIP_TRY(hipGetLastError());
-    }
     return CALIB_OK;
+}
+
+int launch_update_backsub(calib_handle_s* h) {
+    if (h->dtype == CALIB_DTYPE_F64)
+        return h->L == 10 ? launch_update_backsub_t<10, double>(h) : launch_update_backsub_t<9, double>(h);
+    return h->L == 10 ? launch_update_backsub_t<10, float>(h) : launch_update_backsub_t<9, float>(h);
 }
 
 int need_problem(calib_handle_s* h) {
@@ -581,6 +578,7 @@ int calib_lm_begin(calib_handle_t h, const double* P0, int max_iters, double lam
     if (max_iters <= 0)
         return fail(CALIB_E_INVALID, "max_iters must be >= 1 (the reference raises UnboundLocalError "
                                      "for maxIters=0, src/calibrate.py:171)");
+    if (h->M == 0) return fail(CALIB_E_INVALID, "no views to refine");
     if (h->nv != h->M)
         return fail(CALIB_E_SINGULAR, "a view without points makes J^T J + lambda diag(J^T J) singular");
     const size_t ts = tsize(h);
@@ -594,7 +592,7 @@ int calib_lm_begin(calib_handle_t h, const double* P0, int max_iters, double lam
     if (!h->red) h->red = h->red_own.p;
     HIP_TRY(h->P[0].alloc((size_t)K));
     HIP_TRY(h->P[1].alloc((size_t)K));
-    HIP_TRY(h->st.alloc(1));
+    HIP_TRY(h->st.alloc(2));
     HIP_TRY(h->trace.alloc((size_t)max_iters * (CALIB_TRACE_HEADER + h->L)));
     HIP_TRY(hipMemsetAsync(h->trace.p, 0, (size_t)max_iters * (CALIB_TRACE_HEADER + h->L) * 8, h->stream));
     HIP_TRY(hipMemcpyAsync(h->P[0].p, P0, (size_t)K * 8, hipMemcpyHostToDevice, h->stream));
@@ -604,6 +602,7 @@ int calib_lm_begin(calib_handle_t h, const double* P0, int max_iters, double lam
     s.lam = lam_init; s.lam_min = lam_min; s.lam_max = lam_max; s.err_min = err_min;
     s.cur = 1;            // round 0 evaluates the "candidate" buffer 0 == P0
     s.max_iters = max_iters;
+    HIP_TRY(hipMemsetAsync(h->st.p, 0, 2 * sizeof(LMState), h->stream));
     HIP_TRY(hipMemcpyAsync(h->st.p, &s, sizeof(s), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));     // s and P0 are host stack / caller memory
     h->lm_active = true;
@@ -615,34 +614,39 @@ int calib_lm_begin(calib_handle_t h, const double* P0, int max_iters, double lam
 int calib_lm_local(calib_handle_t h) {
     CHECK_H(h);
     if (!h->lm_active) return fail(CALIB_E_STATE, "calib_lm_begin has not been called");
-    int rc = launch_view_setup_any(h, h->P[0].p, h->P[1].p, h->st.p, 1);
-    if (rc) return rc;
-    if (h->lm_mode == CALIB_LM_FUSED) {
-        rc = launch_fused(h, h->st.p, 1);
+    LMState* st = st_cur(h);
+    int rc = CALIB_OK;
+    if (h->rounds_enqueued == 0) {      // later rounds: the update kernel already wrote the candidate's constants
+        rc = launch_view_setup_any(h, h->P[0].p, h->P[1].p, st, 1);
         if (rc) return rc;
-        return launch_schur_reduce(h, h->st.p, h->red);
+    }
+    if (h->lm_mode == CALIB_LM_FUSED) {
+        rc = launch_fused(h, st, 1);
+        if (rc) return rc;
+        return launch_schur_reduce(h, st, h->red);
     }
     for (const auto& c : h->chunks) {
-        rc = launch_jacobian(h, h->P[0].p, h->P[1].p, h->st.p, 1, true, true, false, false, c.p0, c.p1);
+        rc = launch_jacobian(h, h->P[0].p, h->P[1].p, st, 1, true, true, false, false, c.p0, c.p1);
         if (rc) return rc;
-        rc = launch_gram(h, h->st.p, 1, c.item0, c.item1, c.p0);
+        rc = launch_gram(h, st, 1, c.item0, c.item1, c.p0);
         if (rc) return rc;
     }
-    return launch_schur_reduce(h, h->st.p, h->red);
+    return launch_schur_reduce(h, st, h->red);
 }
 
 int calib_lm_update(calib_handle_t h) {
     CHECK_H(h);
     if (!h->lm_active) return fail(CALIB_E_STATE, "calib_lm_begin has not been called");
+    const int rc = launch_update_backsub(h);
     h->rounds_enqueued += 1;
-    return launch_update_backsub(h);
+    return rc;
 }
 
 int calib_lm_done(calib_handle_t h, int* out_done) {
     CHECK_H(h);
     if (!h->lm_active || !out_done) return fail(CALIB_E_STATE, "no LM run active");
     LMState s;
-    HIP_TRY(hipMemcpyAsync(&s, h->st.p, sizeof(s), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(&s, st_cur(h), sizeof(s), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     *out_done = s.done;
     return CALIB_OK;
@@ -654,7 +658,7 @@ int calib_lm_peek_trace(calib_handle_t h, int iter, double* out_row, int* out_it
     if (iter < 0 || iter >= h->lm_max_iters) return fail(CALIB_E_INVALID, "trace row out of range");
     LMState s;
     const size_t w = (size_t)(CALIB_TRACE_HEADER + h->L);
-    HIP_TRY(hipMemcpyAsync(&s, h->st.p, sizeof(s), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(&s, st_cur(h), sizeof(s), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(out_row, h->trace.p + (size_t)iter * w, w * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     *out_iters = s.iters;
@@ -684,7 +688,7 @@ int calib_lm_end(calib_handle_t h, double* P_out, double* out_sse, int* out_iter
     if (!h->lm_active) return fail(CALIB_E_STATE, "no LM run active");
     HIP_TRY(hipStreamSynchronize(h->stream));
     LMState s;
-    HIP_TRY(hipMemcpy(&s, h->st.p, sizeof(s), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&s, st_cur(h), sizeof(s), hipMemcpyDeviceToHost));
     h->lm_active = false;
     if (s.error == CALIB_E_SINGULAR)
         return fail(CALIB_E_SINGULAR, "Singular matrix: damped normal equations are not invertible");
@@ -716,7 +720,7 @@ int calib_lm_step_delta(calib_handle_t h, const double* P, double lambda, double
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     LMState s;
-    HIP_TRY(hipMemcpy(&s, h->st.p, sizeof(s), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&s, st_cur(h), sizeof(s), hipMemcpyDeviceToHost));
     h->lm_active = false;
     if (s.error == CALIB_E_SINGULAR)
         return fail(CALIB_E_SINGULAR, "Singular matrix: damped normal equations are not invertible");

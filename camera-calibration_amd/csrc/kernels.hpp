@@ -1,13 +1,14 @@
 // HIP kernels of the LM refinement engine (gfx950 / CDNA4, wave64).
 //
-// One LM round on one shard (see calib_lm.hip for the launch order):
-//   view_setup   per view: Euler(deg) -> R, t, rotation-derivative axes      [M threads]
-//   jacobian     per point: residual + 2xC Jacobian block -> HBM, sum r^2    [HBM-bound]
-//   gram         per view: 16x16 J^T J and J^T r via v_mfma_f64_16x16x4_f64  [HBM-bound read of J]
-//   schur        per view: 6x6 Cholesky elimination, block partial sums
-//   reduce       fixed-order sum of block partials -> reduce buffer (all-reduced across shards)
-//   update       accept/reject, lambda, L x L solve                          [1 thread]
-//   backsub      per view: delta_i, writes the next candidate P
+// One LM round on one shard (launch order in calib_lm.hip: calib_lm_local / calib_lm_update):
+//   fused            per view item: residuals + 2xC Jacobian blocks in registers -> LDS transpose ->
+//                    16x16 J^T J, J^T r, sum r^2 via v_mfma_f64_16x16x4_f64        [fp64-ALU-bound]
+//     (two-kernel mode instead: jacobian -> compact J in HBM -> gram               [HBM-bound])
+//   schur            per view: 6x6 Cholesky elimination; sum E Vh^-1 [E^T|g] = W^T W via MFMA
+//   reduce           fixed-order sum of block partials -> reduce buffer (all-reduced across shards)
+//   update_backsub   every 16-lane group: accept/reject + L x L solve (redundantly, double-buffered
+//                    state), its view's delta_i, the next candidate P and its view constants
+// view_setup (Euler(deg) -> R, t, derivative axes) runs stand-alone only for round 0 and calib_eval.
 #pragma once
 #include "point_model.hpp"
 #include <stdint.h>
@@ -646,6 +647,15 @@ __global__ __launch_bounds__(256) void sse_reduce_kernel(const double* __restric
     if (tid == 0) out[0] = ssum[0];
 }
 
+// sum over the 16 lanes of a view group
+__device__ __forceinline__ double group_sum16(double v) {
+    v += __shfl_xor(v, 1, 16);
+    v += __shfl_xor(v, 2, 16);
+    v += __shfl_xor(v, 4, 16);
+    v += __shfl_xor(v, 8, 16);
+    return v;
+}
+
 // ---------------------------------------------------------------- N x N solve on 16 lanes
 // Gauss-Jordan with partial pivoting; lane i < N owns row i of [S | s] (row[N] = rhs), lanes >= N
 // hold zero rows. On return the lane that served as pivot row for column myCol holds x[myCol] in d
@@ -685,104 +695,131 @@ __device__ __forceinline__ bool gauss_jordan16(double (&row)[N + 1], int i, int&
     return singular;
 }
 
-// ---------------------------------------------------------------- update (16 lanes)
-// The control flow of src/calibrate.py:155-168 on the device, then the L x L solve
-// (J^T J + lam diag)^-1 restricted to the shared block: S dc = s. Lane i owns row i of [S | s];
+// ---------------------------------------------------------------- update (16 lanes, device function)
+// The control flow of src/calibrate.py:155-168 and the L x L solve S dc = s of the shared block.
+// The LM state is double-buffered per round (in: this round's, out: next round's), so EVERY
+// 16-lane group of the update kernel below can run this redundantly from the same inputs and
+// reach the same decision with no grid-wide hand-off; only the `writer` group stores the new
+// state, the trace row and the shared part of the next candidate. Lane i owns row i of [S | s];
 // Gauss-Jordan with partial pivoting across lanes (np.linalg.inv in the reference is LU with
-// partial pivoting as well). Every lane takes the same scalar decisions; lanes 0..15 write.
+// partial pivoting too). Returns false when the loop is over (nothing left to back-substitute).
 template <int L>
-__global__ __launch_bounds__(64) void update_kernel(LMState* __restrict__ st, const double* __restrict__ red,
-                                                    double* __restrict__ P0, double* __restrict__ P1,
-                                                    double* __restrict__ trace) {
+__device__ __forceinline__ bool lm_update_step(const LMState* __restrict__ in, LMState* __restrict__ out,
+                                               const double* __restrict__ red, double* __restrict__ P0,
+                                               double* __restrict__ P1, double* __restrict__ trace,
+                                               bool writer, int i, int& cur_out, double& lam_out,
+                                               double (&dc)[L]) {
     constexpr int VA = variantSize(L);
     constexpr int kNfail = 2 * L * L + 2 * L, kSse = kNfail + 1;
-    if (st->done) return;
-    const int lane = threadIdx.x, i = lane & 15;
-    const bool writer = lane < 16;
+    const bool w0 = writer && i == 0;
+    if (in->done) {                                  // keep the finished state visible to later rounds
+        if (writer) for (int j = i; j < (int)(sizeof(LMState) / 8); j += 16)
+            reinterpret_cast<double*>(out)[j] = reinterpret_cast<const double*>(in)[j];
+        return false;
+    }
     double* Pb[2] = {P0, P1};
-    int cur = st->cur;
+    int cur = in->cur;
     const int cand = cur ^ 1;
-    const int round = st->round;
+    const int round = in->round;
     const double err_cand = red[kSse];
-    double lam = st->lam;
+    double lam = in->lam;
     const double* sys = red;
     bool done = false;
+    double err_cur_new = err_cand, last_err = err_cand;
+    int iters = in->iters, accepted = 0;
     if (round == 0) {
         cur = cand;
-        if (lane == 0) { st->cur = cur; st->err_cur = err_cand; st->last_err = err_cand; }
     } else {
         const int it = round - 1;
-        const double err_cur = st->err_cur;
-        const bool acc = err_cand < err_cur;      // strict; NaN rejects (src/calibrate.py:161)
+        const double err_cur = in->err_cur;
+        const bool acc = err_cand < err_cur;         // strict; NaN rejects (src/calibrate.py:161)
         if (trace && writer) {
             double* row = trace + (int64_t)it * (5 + L);
             if (i < L) row[5 + i] = Pb[cur][i];
             if (i == 0) { row[0] = it; row[1] = err_cur; row[2] = err_cand; row[3] = lam; row[4] = acc ? 1.0 : 0.0; }
         }
         if (acc) { cur = cand; lam = lam / 10; } else { lam = lam * 10; sys = red + VA; }
-        done = !(st->lam_min < lam && lam < st->lam_max) || err_cur < st->err_min || it + 1 >= st->max_iters;
-        if (lane == 0) {
-            st->last_err = err_cur;               // the reference returns the pre-update error (:155,171)
-            if (acc) { st->cur = cur; st->err_cur = err_cand; }
-            st->lam = lam;
-            st->iters = it + 1;
-            st->accepted_last = acc ? 1 : 0;
-        }
+        done = !(in->lam_min < lam && lam < in->lam_max) || err_cur < in->err_min || it + 1 >= in->max_iters;
+        last_err = err_cur;                          // the reference returns the pre-update error (:155,171)
+        err_cur_new = acc ? err_cand : err_cur;
+        iters = it + 1;
+        accepted = acc ? 1 : 0;
     }
-    if (lane == 0) { st->round = round + 1; if (done) st->done = 1; }
-    if (done) return;
-    if (sys[kNfail] > 0.0) { if (lane == 0) { st->error = -3; st->done = 1; } return; }
+    int error = 0;
+    if (!done && sys[kNfail] > 0.0) { error = -3; done = true; }
 
     // B and g_c of the parameters the step starts from: variant A carries them for a freshly
     // accepted (or the bootstrap) point, which also becomes the state's copy; after a rejection
     // the state's copy of the unchanged current point is used.
     const bool fresh = sys == red;
-    const double* Bm = fresh ? red : st->B;
-    const double* gcv = fresh ? red + 2 * L * L : st->gc;
-    // row i of S = B + lam diag(B) - sum E Vh^-1 E^T, rhs s = g_c - sum E Vh^-1 g_v
-    double row[L + 1];
+    const double* Bm = fresh ? red : in->B;
+    const double* gcv = fresh ? red + 2 * L * L : in->gc;
+    double row[L + 1], brow[L];
+    double gci = 0.0;
 #pragma unroll
     for (int j = 0; j <= L; ++j) row[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < L; ++j) brow[j] = 0.0;
     if (i < L) {
-        double brow[L];
 #pragma unroll
         for (int j = 0; j < L; ++j) brow[j] = Bm[i * L + j];
-        const double gci = gcv[i];
+        gci = gcv[i];
+        // row i of S = B + lam diag(B) - sum E Vh^-1 E^T, rhs s = g_c - sum E Vh^-1 g_v
 #pragma unroll
         for (int j = 0; j < L; ++j) row[j] = brow[j] - sys[L * L + i * L + j];
         row[L] = gci - sys[2 * L * L + L + i];
 #pragma unroll
         for (int j = 0; j < L; ++j) if (j == i) row[j] += lam * brow[j];
-        if (fresh && writer) {
+    }
+    int myCol = -1;
+    double d = 0.0;
+    if (!done && gauss_jordan16<L>(row, i, myCol, d)) { error = -3; done = true; }
 #pragma unroll
-            for (int j = 0; j < L; ++j) st->B[i * L + j] = brow[j];
-            st->gc[i] = gci;
+    for (int c = 0; c < L; ++c) dc[c] = group_sum16(myCol == c ? d : 0.0);
+
+    if (writer) {
+        if (i < L) {
+#pragma unroll
+            for (int j = 0; j < L; ++j) out->B[i * L + j] = brow[j];      // (fresh ? new : unchanged) copy
+            out->gc[i] = gci;
+            double dci = 0.0;
+#pragma unroll
+            for (int c = 0; c < L; ++c) if (c == i) dci = dc[c];
+            out->dc[i] = dci;
+            if (!done) Pb[cur ^ 1][i] = Pb[cur][i] + dci;
+        }
+        if (w0) {
+            out->lam = lam; out->err_cur = err_cur_new; out->last_err = last_err;
+            out->lam_min = in->lam_min; out->lam_max = in->lam_max; out->err_min = in->err_min;
+            out->cur = cur; out->round = round + 1; out->iters = iters; out->max_iters = in->max_iters;
+            out->done = done ? 1 : 0; out->error = error; out->accepted_last = accepted; out->pad = 0;
         }
     }
-    int myCol;
-    double d;
-    if (gauss_jordan16<L>(row, i, myCol, d)) { if (lane == 0) { st->error = -3; st->done = 1; } return; }
-    if (writer && myCol >= 0) {
-        st->dc[myCol] = d;
-        Pb[cur ^ 1][myCol] = Pb[cur][myCol] + d;
-    }
+    cur_out = cur;
+    lam_out = lam;
+    return !done;
 }
 
-// ---------------------------------------------------------------- back-substitution
-// delta_i = Vh^-1 (g_i - E_i^T dc); next candidate P[cur^1] = P[cur] + delta.
-template <int L>
-__global__ __launch_bounds__(kSchurThreads) void backsub_kernel(const double* __restrict__ G0,
-                                                                const double* __restrict__ G1,
-                                                                const LMState* __restrict__ st,
-                                                                const int* __restrict__ view_item0,
-                                                                const int* __restrict__ view_ext, int nv,
-                                                                double* __restrict__ P0,
-                                                                double* __restrict__ P1) {
-    if (st->done) return;
+// ---------------------------------------------------------------- update + back-substitution + next view constants
+// One launch per LM round after the reduce (and, across GPUs, the all-reduce): every 16-lane
+// group (a) takes the accept/reject decision and solves for dc (lm_update_step, redundantly),
+// (b) back-substitutes its view, delta_i = Vh^-1 (g_i - E_i^T dc), and writes the view's part of
+// the next candidate P[cur^1] = P[cur] + delta, (c) turns the candidate's Euler angles (degrees)
+// into the rotation / derivative-axis constants the next round's point kernels read (what
+// view_setup_kernel does for round 0).
+template <int L, typename T>
+__global__ __launch_bounds__(kSchurThreads) void update_backsub_kernel(
+        const double* __restrict__ G0, const double* __restrict__ G1, const LMState* __restrict__ st_in,
+        LMState* __restrict__ st_out, const double* __restrict__ red, const int* __restrict__ view_item0,
+        const int* __restrict__ view_ext, int nv, double* __restrict__ P0, double* __restrict__ P1,
+        double* __restrict__ trace, T* __restrict__ VC) {
     const int tid = threadIdx.x, c = tid & 15;
     const int v = blockIdx.x * (kSchurThreads / 16) + (tid >> 4);
+    const bool writer = blockIdx.x == 0 && tid < 16;
+    int cur;
+    double lam, dc[L];
+    if (!lm_update_step<L>(st_in, st_out, red, P0, P1, trace, writer, c, cur, lam, dc)) return;
     if (v >= nv) return;       // whole 16-lane group leaves together
-    const int cur = st->cur;
     const double* G = cur ? G1 : G0;
     const double* Pc = cur ? P1 : P0;
     double* Pn = cur ? P0 : P1;
@@ -790,18 +827,13 @@ __global__ __launch_bounds__(kSchurThreads) void backsub_kernel(const double* __
     const int i0 = view_item0[v];
     load_view_col(G, i0, view_item0[v + 1] - i0, c, col, gc, sse);
     Elim<L> e;
-    eliminate<L>(col, gc, st->lam, e);
-    const double dcc = c < L ? st->dc[c] : 0.0;
+    eliminate<L>(col, gc, lam, e);
+    double dcc = 0.0;
+#pragma unroll
+    for (int j = 0; j < L; ++j) if (j == c) dcc = dc[j];
     double w[6];
 #pragma unroll
-    for (int m = 0; m < 6; ++m) {
-        double t = dcc * e.z[m];
-        t += __shfl_xor(t, 1, 16);
-        t += __shfl_xor(t, 2, 16);
-        t += __shfl_xor(t, 4, 16);
-        t += __shfl_xor(t, 8, 16);
-        w[m] = e.zg[m] - t;
-    }
+    for (int m = 0; m < 6; ++m) w[m] = e.zg[m] - group_sum16(dcc * e.z[m]);
     // Lc^T d = w
     double d[6];
 #pragma unroll
@@ -811,13 +843,36 @@ __global__ __launch_bounds__(kSchurThreads) void backsub_kernel(const double* __
         for (int n = m + 1; n < 6; ++n) t -= e.Lc[tri(n, m)] * d[n];
         d[m] = t * e.invd[m];
     }
-    if (c < 6) {
-        const int64_t o = L + 6 * (int64_t)view_ext[v] + c;
-        double dv = d[0];
+    const int64_t o = L + 6 * (int64_t)view_ext[v];
+    double en[6];
 #pragma unroll
-        for (int m = 1; m < 6; ++m) dv = (c == m) ? d[m] : dv;
-        Pn[o] = Pc[o] + dv;
+    for (int m = 0; m < 6; ++m) en[m] = Pc[o + m] + d[m];
+    if (c < 6) {
+        double ev = en[0];
+#pragma unroll
+        for (int m = 1; m < 6; ++m) ev = (c == m) ? en[m] : ev;
+        Pn[o + c] = ev;
     }
+    // view constants of the candidate (layout of view_setup_kernel)
+    const double deg = 0.017453292519943295;
+    double sn[3], cs[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double th = en[a] * deg;
+        sincos(th, &sn[a], &cs[a]);
+        if (fabs(th) <= 1e-8) { sn[a] = 0.0; cs[a] = 1.0; }
+    }
+    const double sx = sn[0], cx = cs[0], sy = sn[1], cy = cs[1], sz = sn[2], cz = cs[2];
+    const double o18[18] = {cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx,
+                            sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx,
+                            -sy, cy * sx, cy * cx, en[3], en[4], en[5],
+                            deg * cz * cy, deg * sz * cy, -deg * sy, -deg * sz, deg * cz, 0.0};
+    double mine = o18[0];
+#pragma unroll
+    for (int j = 1; j < 16; ++j) mine = (c == j) ? o18[j] : mine;
+    T* dst = VC + (int64_t)v * kViewStride;
+    dst[c] = (T)mine;
+    if (c < 2) dst[16 + c] = (T)(c == 0 ? o18[16] : o18[17]);
 }
 
 // ---------------------------------------------------------------- per-view homography LM
@@ -827,14 +882,6 @@ __global__ __launch_bounds__(kSchurThreads) void backsub_kernel(const double* __
 // With p = (X, Y, 1)/w, the 9-column Jacobian rows of HomographyJacobian (src/jacobian.py:88-121)
 // are Ju = (p, 0, -u p), Jv = (0, p, -v p), so J^T J = [[A,0,-uA],[0,A,-vA],[.,.,(u^2+v^2)A]] with
 // A = p p^T: 24 sums + 9 gradient sums + the error per pass, reduced across the 16 lanes.
-__device__ __forceinline__ double group_sum16(double v) {
-    v += __shfl_xor(v, 1, 16);
-    v += __shfl_xor(v, 2, 16);
-    v += __shfl_xor(v, 4, 16);
-    v += __shfl_xor(v, 8, 16);
-    return v;
-}
-
 __global__ __launch_bounds__(256) void homography_lm_kernel(const int64_t* __restrict__ offs,
                                                             const double2* __restrict__ uv,
                                                             const double2* __restrict__ XY, int64_t M,
