@@ -245,7 +245,7 @@ LMState* st_next(calib_handle_s* h) { return h->st.p + ((h->rounds_enqueued + 1)
 template <int L, typename T>
 int launch_update_backsub_t(calib_handle_s* h) {
     const int per = kSchurThreads / 16;
-    const int blocks = std::max(1, (h->nv + per - 1) / per);
+    const int blocks = std::max(1, std::min(2048, (h->nv + per - 1) / per));     // grid-stride over views
     hipLaunchKernelGGL((update_backsub_kernel<L, T>), dim3(blocks), dim3(kSchurThreads), 0, h->stream, h->G[0].p,
                        h->G[1].p, st_cur(h), st_next(h), h->red, h->view_item0.p, h->view_ext.p, h->nv,
                        h->P[0].p, h->P[1].p, h->trace.p, reinterpret_cast<T*>(h->VC.p));

@@ -801,8 +801,9 @@ __device__ __forceinline__ bool lm_update_step(const LMState* __restrict__ in, L
 }
 
 // ---------------------------------------------------------------- update + back-substitution + next view constants
-// One launch per LM round after the reduce (and, across GPUs, the all-reduce): every 16-lane
-// group (a) takes the accept/reject decision and solves for dc (lm_update_step, redundantly),
+// One launch per LM round after the reduce (and, across GPUs, the all-reduce): every workgroup
+// (a) takes the accept/reject decision and solves for dc (lm_update_step, redundantly, one 16-lane
+// group per workgroup), then every 16-lane group
 // (b) back-substitutes its view, delta_i = Vh^-1 (g_i - E_i^T dc), and writes the view's part of
 // the next candidate P[cur^1] = P[cur] + delta, (c) turns the candidate's Euler angles (degrees)
 // into the rotation / derivative-axis constants the next round's point kernels read (what
@@ -814,15 +815,33 @@ __global__ __launch_bounds__(kSchurThreads) void update_backsub_kernel(
         const int* __restrict__ view_ext, int nv, double* __restrict__ P0, double* __restrict__ P1,
         double* __restrict__ trace, T* __restrict__ VC) {
     const int tid = threadIdx.x, c = tid & 15;
-    const int v = blockIdx.x * (kSchurThreads / 16) + (tid >> 4);
     const bool writer = blockIdx.x == 0 && tid < 16;
-    int cur;
-    double lam, dc[L];
-    if (!lm_update_step<L>(st_in, st_out, red, P0, P1, trace, writer, c, cur, lam, dc)) return;
-    if (v >= nv) return;       // whole 16-lane group leaves together
+    // the first 16-lane group of every workgroup takes the decision and solves; the others get
+    // (go, cur, lambda, dc) through LDS
+    __shared__ double sdec[L + 3];
+    int cur = 0;
+    double lam = 0.0, dc[L];
+    if (tid < 16) {
+        const bool go = lm_update_step<L>(st_in, st_out, red, P0, P1, trace, writer, c, cur, lam, dc);
+        if (c == 0) { sdec[0] = go ? 1.0 : 0.0; sdec[1] = (double)cur; sdec[2] = lam; }
+        if (c < L) {
+            double dci = 0.0;
+#pragma unroll
+            for (int j = 0; j < L; ++j) if (j == c) dci = dc[j];
+            sdec[3 + c] = dci;
+        }
+    }
+    __syncthreads();
+    if (sdec[0] == 0.0) return;
+    cur = (int)sdec[1];
+    lam = sdec[2];
+#pragma unroll
+    for (int j = 0; j < L; ++j) dc[j] = sdec[3 + j];
     const double* G = cur ? G1 : G0;
     const double* Pc = cur ? P1 : P0;
     double* Pn = cur ? P0 : P1;
+    // grid-stride over views: the decision / solve above is paid once per workgroup, not per view
+    for (int v = blockIdx.x * (kSchurThreads / 16) + (tid >> 4); v < nv; v += gridDim.x * (kSchurThreads / 16)) {
     double col[16], gc, sse;
     const int i0 = view_item0[v];
     load_view_col(G, i0, view_item0[v + 1] - i0, c, col, gc, sse);
@@ -855,12 +874,16 @@ __global__ __launch_bounds__(kSchurThreads) void update_backsub_kernel(
     }
     // view constants of the candidate (layout of view_setup_kernel)
     const double deg = 0.017453292519943295;
+    // one sincos per wave instruction stream: lane a (< 3) of the group takes angle a, the results
+    // are handed round by shuffles
     double sn[3], cs[3];
+    {
+        const double th = (c == 1 ? en[1] : (c == 2 ? en[2] : en[0])) * deg;
+        double s1, c1;
+        sincos(th, &s1, &c1);
+        if (fabs(th) <= 1e-8) { s1 = 0.0; c1 = 1.0; }
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const double th = en[a] * deg;
-        sincos(th, &sn[a], &cs[a]);
-        if (fabs(th) <= 1e-8) { sn[a] = 0.0; cs[a] = 1.0; }
+        for (int a = 0; a < 3; ++a) { sn[a] = __shfl(s1, a, 16); cs[a] = __shfl(c1, a, 16); }
     }
     const double sx = sn[0], cx = cs[0], sy = sn[1], cy = cs[1], sz = sn[2], cz = cs[2];
     const double o18[18] = {cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx,
@@ -873,6 +896,7 @@ __global__ __launch_bounds__(kSchurThreads) void update_backsub_kernel(
     T* dst = VC + (int64_t)v * kViewStride;
     dst[c] = (T)mine;
     if (c < 2) dst[16 + c] = (T)(c == 0 ? o18[16] : o18[17]);
+    }
 }
 
 // ---------------------------------------------------------------- per-view homography LM
