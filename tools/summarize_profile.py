@@ -26,8 +26,14 @@ def shortName(n):
     return n.split("(")[0]
 
 
+def newest(pattern):
+    files = glob.glob(pattern, recursive=True)
+    return max(files, key=os.path.getmtime) if files else None
+
+
 def lastPerKernel(folder, counter):
-    files = glob.glob(os.path.join(folder, "**", "*counter_collection.csv"), recursive=True)
+    # gpurun merges every run's files into the same local folder: only the newest run counts
+    files = [newest(os.path.join(folder, "**", "*counter_collection.csv"))]
     out = {}
     for f in files:
         for row in csv.DictReader(open(f)):
@@ -47,7 +53,7 @@ def main():
     a = ap.parse_args()
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     if a.stats:
-        f = glob.glob(os.path.join(a.stats, "**", "*kernel_stats.csv"), recursive=True)[0]
+        f = newest(os.path.join(a.stats, "**", "*kernel_stats.csv"))
         shutil.copy(f, os.path.join(ROOT, "profiles", f"{a.tag}_kernel_stats.csv"))
     if a.fetch and a.write:
         fetch = lastPerKernel(a.fetch, "FETCH_SIZE")
