@@ -280,7 +280,7 @@ def main():
             "config": {"workload": f"{args.workload}: {viewsPerGpu} views x {shard['pointsPerView']} pts per GPU, "
                                    f"{cfg['model']}, {cfg['dtype']}, sensor noise {args.noise} px",
                        "views_per_gpu": viewsPerGpu, "points_per_view": shard["pointsPerView"],
-                       "global_points": MNglobal, "model": cfg["model"], "parallelism": f"views-sharded x{world}",
+                       "global_points": MNglobal, "distortion": cfg["model"], "parallelism": f"views-sharded x{world}",
                        "lm_mode": args.lm_mode},
             "roofline": mainRoof,
             "roofline_jacobian_kernel": jacRoof,
