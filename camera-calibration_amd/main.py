@@ -1,21 +1,26 @@
-"""User-facing facade (reference: src/main.py:11-36)."""
+"""User-facing entry point: one call from detections to (sse, A, W, k).
+
+Same name, arguments and return value as the reference's facade (src/main.py:11-36), so callers
+only change their import.
+"""
 from . import calibrate
 from . import distortion
 
+_MODELS = {
+    "radtan": distortion.RadialTangentialModel,
+    "fisheye": distortion.FisheyeModel,
+}
+
 
 def calibrateCamera(allDetections: list, distortionType: str, maxIters, **engineOptions) -> tuple:
-    """Intrinsic matrix, distortion coefficients and board poses from a set of detections.
+    """allDetections: per view a (sensorPoints (N,2), modelPoints (N,3)) pair; distortionType one of
+    "radtan", "fisheye"; engineOptions: dtype="f64"|"f32", device=<HIP device> (extras).
 
-    allDetections -- list of (sensorPoints (N,2), modelPoints (N,3)), one per view
-    distortionType -- "radtan" or "fisheye"
-    engineOptions -- dtype="f64"|"f32", device=<HIP device index> (extras over the reference)
-    -> (sse, Afinal (3,3), Wfinal list of (4,4), kFinal)
-    """
-    if distortionType == "radtan":
-        distortionModel = distortion.RadialTangentialModel()
-    elif distortionType == "fisheye":
-        distortionModel = distortion.FisheyeModel()
-    else:
-        raise ValueError(f"Distortion type: {distortionType} unknown")
-    calibrator = calibrate.Calibrator(distortionModel, **engineOptions)
-    return calibrator.calibrate(allDetections, maxIters)
+    Host closed-form initialisation, then the Levenberg-Marquardt refinement on the GPU.
+    Returns the final sum of squared errors, the intrinsic matrix (3,3), the list of world-to-camera
+    transforms (4,4) and the distortion coefficients."""
+    try:
+        modelClass = _MODELS[distortionType]
+    except KeyError:
+        raise ValueError(f"Distortion type: {distortionType} unknown") from None
+    return calibrate.Calibrator(modelClass(), **engineOptions).calibrate(allDetections, maxIters)
