@@ -5,6 +5,7 @@ visible, every compute entry point raises.
 """
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -70,6 +71,15 @@ def loadLibrary():
     global _lib
     if _lib is not None:
         return _lib
+    if "torch" not in sys.modules:
+        # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so). When this library is
+        # loaded first it binds /opt/rocm's copy and a later `import torch` finds no devices
+        # ("No HIP GPUs are available"); with torch first, both share torch's runtime. torch is
+        # only plumbing here (streams, torch.distributed), so a missing torch is not an error.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise CalibNativeError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

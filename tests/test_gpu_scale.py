@@ -195,3 +195,63 @@ def test_c5_shape_single_shard_sample():
     n = min(6, iters)
     assert np.array_equal(trace[:n, 3], trO[:n, 3]) and np.allclose(trace[:n, 1], trO[:n, 1], rtol=1e-9)
     eng.close()
+
+
+@pytest.mark.parametrize("name,model,seed", [("radtan", orc.RADTAN, 1), ("fisheye", orc.FISHEYE, 2), ("radtan", orc.RADTAN, 3)])
+def test_random_ragged_views_vs_c_oracle(name, model, seed):
+    """Ragged problems with awkward sizes (3..700 points per view: below / at / above the 4-point
+    group, the 64-lane batch, the 256-point tile and the 512-point item; general 3-D model points)
+    against the C oracle on the same inputs."""
+    from oracle import c_oracle
+    if not c_oracle.available():
+        pytest.skip("oracle/libcalib_oracle.so not built")
+    rng = np.random.default_rng(seed)
+    sizes = np.concatenate(([3, 4, 5, 63, 64, 65, 255, 256, 257, 511, 512, 513, 700], rng.integers(3, 200, 60)))
+    rng.shuffle(sizes)
+    M = sizes.shape[0]
+    offs = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+    MN = int(offs[-1])
+    cfg = synthetic.CONFIGS["c2" if name == "radtan" else "c3"]
+    corners = synthetic.checkerboardCorners(25, 18, 0.02)
+    W = synthetic.sampleBoardPosesInCamera(corners, np.arange(100, 100 + M))
+    Ptrue = synthetic.composeP(cfg["A"], W, cfg["k"])
+    pts = np.vstack([np.column_stack((rng.uniform(0, 0.48, n), rng.uniform(0, 0.34, n), rng.uniform(-0.01, 0.01, n)))
+                     for n in sizes])
+    L = orc.numShared(model)
+    sensor = c_oracle.evaluate(model, Ptrue, offs, None, pts)["y"] + rng.normal(0, 0.05, (MN, 2))
+    P0 = Ptrue * (1 + 1e-3 * rng.standard_normal(Ptrue.shape[0]))
+    for mode in ("fused", "two_kernel"):
+        eng = cca.RefineEngine(name, "f64")
+        eng.setProblem(offs, sensor, pts)
+        eng.setLmMode(mode)
+        ev = eng.evaluate(P0, wantY=True, wantR=True, wantJ=True)
+        eo = c_oracle.evaluate(model, P0, offs, sensor, pts, wantJ=True)
+        assert np.abs(ev["y"] - eo["y"]).max() < 1e-9
+        scale = np.abs(eo["Jc"]).reshape(-1, L + 6).max(axis=0)
+        assert (np.abs(ev["Jc"] - eo["Jc"]).reshape(-1, L + 6).max(axis=0) / scale).max() < 1e-11
+        assert abs(ev["sse"] - eo["sse"]) <= 1e-11 * eo["sse"]
+        d = eng.stepDelta(P0, 1e-3)
+        do = c_oracle.step(model, P0, offs, sensor, pts, 1e-3)
+        assert np.linalg.norm(d - do) <= 1e-8 * np.linalg.norm(do)
+        sse, P, iters, trace = eng.refine(P0, 30)
+        sseO, PO, trO = c_oracle.refine(model, P0, offs, sensor, pts, 30)
+        assert abs(sse - sseO) <= 1e-8 * sseO
+        n = min(5, iters, trO.shape[0])
+        assert np.array_equal(trace[:n, 3], trO[:n, 3]) and np.allclose(trace[:n, 1:3], trO[:n, 1:3], rtol=1e-9)
+        assert relIntr(P, PO, L) < 1e-7
+        eng.close()
+
+
+def test_nan_candidate_is_rejected_not_propagated():
+    """A step that sends a point behind the camera / to NaN must be rejected (IEEE `<` is false,
+    src/calibrate.py:161) and leave the parameters finite."""
+    sh = synthetic.makeShard("c2", numViews=50, noiseSigma=0.0)
+    offs, s, m = sh["viewOffsets"], sh["sensorPoints"].copy(), sh["modelPoints"]
+    s[7] = np.nan                     # one corrupt detection: every error is NaN
+    eng = cca.RefineEngine("radtan")
+    eng.setProblem(offs, s, m)
+    sse, P, iters, trace = eng.refine(sh["P0"], 6)
+    assert np.isnan(sse) and iters >= 1
+    assert np.all(trace[:, 4] == 0)                      # NaN < NaN is false: never accepted
+    assert np.array_equal(P, sh["P0"])                   # parameters untouched
+    eng.close()
