@@ -337,3 +337,21 @@ def test_homography_lm_on_device_vs_reference():
     A, W, k = cca.Calibrator(cca.RadialTangentialModel()).estimateCalibrationParameters(dets)
     assert np.abs(A - g3["A0"]).max() < 1e-5 and np.abs(np.array(W) - g3["W0"]).max() < 1e-6
     assert np.abs(np.array(k) - g3["k0"]).max() < 1e-5
+
+
+def test_reference_unit_test_call_shapes():
+    """tests/test_calibrate.py:80-100 calls refineCalibrationParameters with a stale signature: a
+    MagicMock lands in maxIters (MagicMock.__index__() == 1) and 1 in shouldPrint. Must keep running."""
+    from unittest.mock import MagicMock
+    g = loadGolden("g3_unittest15.npz")
+    offs = g["viewOffsets"]
+    dets = [(g["sensorPoints"][a:b], g["modelPoints"][a:b]) for a, b in zip(offs[:-1], offs[1:])]
+    cal = cca.Calibrator(cca.RadialTangentialModel())
+    jac = MagicMock()
+    sse, A, W, k = cal.refineCalibrationParameters(g["A0"], list(g["W0"]), tuple(g["k0"]), dets, jac, 1)
+    assert isinstance(sse, float) and A.shape == (3, 3) and len(W) == len(dets) and len(k) == 5
+    # tests/test_calibrate.py:102-121
+    P = cal._composeParameterVector(g["A0"], list(g["W0"]), tuple(g["k0"]))
+    y = cal.projectAllPoints(P, [m for s, m in dets])
+    assert y.shape[0] > 0 and y.shape[1] == 2
+    assert cca.getSensorPoints(dets).shape == y.shape
