@@ -40,8 +40,10 @@ class Calibrator:
     def estimateCalibrationParameters(self, allDetections):
         """src/calibrate.py:41-58: Zhang's closed-form initialisation, on the host."""
         from . import linearcalibrate
-        return linearcalibrate.estimateCalibrationParameters(self._distortionModel, allDetections,
-                                                             refine=self._refineHomographies)
+        offs, sensor, model = engine.packDetections(allDetections)
+        A, W, k = linearcalibrate.estimateCalibrationParametersDevice(self._distortionModel, offs, sensor, model,
+                                                                      self._device)
+        return A, list(W), k
 
     def _refineHomographies(self, Hs, allDetections):
         """LM polish of the DLT homographies, all views in one device launch (src/calibrate.py:60-67)"""

@@ -814,19 +814,36 @@ int calib_project_with_distortion(int model, int64_t n, const double* A, const d
     return CALIB_OK;
 }
 
-int calib_refine_homographies(int64_t num_views, const int64_t* view_offsets, const double* sensor_uv,
-                              const double* model_xyz, double* H_inout, int max_iters, int device_id) {
-    if (num_views < 0 || !view_offsets || !H_inout) return fail(CALIB_E_INVALID, "null argument");
+namespace {
+
+int check_views(int64_t num_views, const int64_t* view_offsets, const double* sensor_uv, const double* model_xyz) {
+    if (num_views < 0 || !view_offsets) return fail(CALIB_E_INVALID, "null argument");
     if (num_views == 0) return CALIB_OK;
     const int64_t MN = view_offsets[num_views];
     if (view_offsets[0] != 0 || MN < 0 || (MN > 0 && (!sensor_uv || !model_xyz)))
         return fail(CALIB_E_INVALID, "bad view_offsets / point arrays");
     for (int64_t i = 0; i < num_views; ++i)
         if (view_offsets[i + 1] < view_offsets[i]) return fail(CALIB_E_INVALID, "view_offsets must be non-decreasing");
+    return CALIB_OK;
+}
+
+int use_device(int device_id) {
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device_id < 0 || device_id >= ndev) return fail(CALIB_E_HIP, "no such HIP device (no CPU fallback)");
     HIP_TRY(hipSetDevice(device_id));
+    return CALIB_OK;
+}
+
+// DLT and / or LM polish of every view's homography
+int homography_pipeline(int64_t num_views, const int64_t* view_offsets, const double* sensor_uv,
+                        const double* model_xyz, double* H, bool dlt, int refine_iters, int device_id) {
+    if (!H) return fail(CALIB_E_INVALID, "null argument");
+    int rc = check_views(num_views, view_offsets, sensor_uv, model_xyz);
+    if (rc || num_views == 0) return rc;
+    rc = use_device(device_id);
+    if (rc) return rc;
+    const int64_t MN = view_offsets[num_views];
     std::vector<double> xy((size_t)MN * 2);
     for (int64_t p = 0; p < MN; ++p) { xy[2 * p] = model_xyz[3 * p]; xy[2 * p + 1] = model_xyz[3 * p + 1]; }
     DevBuf<int64_t> doffs;
@@ -838,17 +855,123 @@ int calib_refine_homographies(int64_t num_views, const int64_t* view_offsets, co
     if (e == hipSuccess) e = hipMemcpy(doffs.p, view_offsets, ((size_t)num_views + 1) * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess && MN) e = hipMemcpy(duv.p, sensor_uv, (size_t)MN * 16, hipMemcpyHostToDevice);
     if (e == hipSuccess && MN) e = hipMemcpy(dxy.p, xy.data(), (size_t)MN * 16, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dH.p, H_inout, (size_t)num_views * 72, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        const unsigned blocks = (unsigned)((num_views + 15) / 16);
-        hipLaunchKernelGGL(homography_lm_kernel, dim3(blocks), dim3(256), 0, 0, doffs.p,
-                           reinterpret_cast<const double2*>(duv.p), reinterpret_cast<const double2*>(dxy.p),
-                           num_views, max_iters, dH.p);
+    if (e == hipSuccess && !dlt) e = hipMemcpy(dH.p, H, (size_t)num_views * 72, hipMemcpyHostToDevice);
+    const unsigned blocks = (unsigned)((num_views + 15) / 16);
+    if (e == hipSuccess && dlt) {
+        hipLaunchKernelGGL(dlt_kernel, dim3(blocks), dim3(256), 0, 0, doffs.p, reinterpret_cast<const double2*>(duv.p),
+                           reinterpret_cast<const double2*>(dxy.p), num_views, dH.p);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpy(H_inout, dH.p, (size_t)num_views * 72, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && refine_iters > 0) {
+        hipLaunchKernelGGL(homography_lm_kernel, dim3(blocks), dim3(256), 0, 0, doffs.p,
+                           reinterpret_cast<const double2*>(duv.p), reinterpret_cast<const double2*>(dxy.p),
+                           num_views, refine_iters, dH.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(H, dH.p, (size_t)num_views * 72, hipMemcpyDeviceToHost);
     doffs.release(); duv.release(); dxy.release(); dH.release();
     if (e != hipSuccess) return fail(CALIB_E_HIP, hipGetErrorString(e));
+    return CALIB_OK;
+}
+
+}  // namespace
+
+int calib_refine_homographies(int64_t num_views, const int64_t* view_offsets, const double* sensor_uv,
+                              const double* model_xyz, double* H_inout, int max_iters, int device_id) {
+    return homography_pipeline(num_views, view_offsets, sensor_uv, model_xyz, H_inout, false, max_iters, device_id);
+}
+
+int calib_estimate_homographies(int64_t num_views, const int64_t* view_offsets, const double* sensor_uv,
+                                const double* model_xyz, double* H_out, int refine_iters, int device_id) {
+    if (num_views > 0 && view_offsets)
+        for (int64_t i = 0; i < num_views; ++i)
+            if (view_offsets[i + 1] - view_offsets[i] < 4)
+                return fail(CALIB_E_INVALID, "a homography needs at least 4 point correspondences per view");
+    return homography_pipeline(num_views, view_offsets, sensor_uv, model_xyz, H_out, true, refine_iters, device_id);
+}
+
+int calib_compute_extrinsics(int64_t num_views, const double* A, const double* H, double* W_out, int device_id) {
+    if (num_views < 0 || !A || (num_views > 0 && (!H || !W_out))) return fail(CALIB_E_INVALID, "null argument");
+    if (num_views == 0) return CALIB_OK;
+    int rc = use_device(device_id);
+    if (rc) return rc;
+    // A = [[a, g, uc], [0, b, vc], [0, 0, 1]] (src/calibrate.py:252-256): closed-form inverse
+    const double a = A[0], g = A[1], uc = A[2], b = A[4], vc = A[5];
+    if (!(a != 0.0) || !(b != 0.0)) return fail(CALIB_E_SINGULAR, "Singular matrix: intrinsic matrix is not invertible");
+    const double Ainv[9] = {1.0 / a, -g / (a * b), (g * vc - uc * b) / (a * b), 0.0, 1.0 / b, -vc / b, 0.0, 0.0, 1.0};
+    DevBuf<double> dA, dH, dW;
+    hipError_t e = dA.alloc(9);
+    if (e == hipSuccess) e = dH.alloc((size_t)num_views * 9);
+    if (e == hipSuccess) e = dW.alloc((size_t)num_views * 16);
+    if (e == hipSuccess) e = hipMemcpy(dA.p, Ainv, 72, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dH.p, H, (size_t)num_views * 72, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(extrinsics_kernel, dim3((unsigned)((num_views + 255) / 256)), dim3(256), 0, 0, dA.p, dH.p,
+                           num_views, dW.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(W_out, dW.p, (size_t)num_views * 128, hipMemcpyDeviceToHost);
+    dA.release(); dH.release(); dW.release();
+    if (e != hipSuccess) return fail(CALIB_E_HIP, hipGetErrorString(e));
+    return CALIB_OK;
+}
+
+int calib_distortion_normal_equations(int model, int64_t num_views, const int64_t* view_offsets,
+                                      const double* sensor_uv, const double* model_xyz, const double* A,
+                                      const double* W, double* out_DtD, double* out_Dtd, int device_id) {
+    if (model != CALIB_MODEL_RADTAN && model != CALIB_MODEL_FISHEYE) return fail(CALIB_E_INVALID, "unknown distortion model");
+    if (!A || !out_DtD || !out_Dtd || (num_views > 0 && !W)) return fail(CALIB_E_INVALID, "null argument");
+    int rc = check_views(num_views, view_offsets, sensor_uv, model_xyz);
+    if (rc) return rc;
+    const int nk = model == CALIB_MODEL_RADTAN ? 5 : 4;
+    const int ns = nk * (nk + 1) / 2 + nk;
+    std::fill(out_DtD, out_DtD + nk * nk, 0.0);
+    std::fill(out_Dtd, out_Dtd + nk, 0.0);
+    const int64_t MN = num_views ? view_offsets[num_views] : 0;
+    if (MN == 0) return CALIB_OK;
+    rc = use_device(device_id);
+    if (rc) return rc;
+    std::vector<double> xy((size_t)MN * 2), z((size_t)MN);
+    std::vector<int> pv((size_t)MN);
+    for (int64_t v = 0; v < num_views; ++v)
+        for (int64_t p = view_offsets[v]; p < view_offsets[v + 1]; ++p) pv[(size_t)p] = (int)v;
+    for (int64_t p = 0; p < MN; ++p) { xy[2 * p] = model_xyz[3 * p]; xy[2 * p + 1] = model_xyz[3 * p + 1]; z[p] = model_xyz[3 * p + 2]; }
+    const int blocks = (int)std::min<int64_t>(1024, (MN + 255) / 256);
+    DevBuf<double> dA, dW, duv, dxy, dz, dpart;
+    DevBuf<int> dpv;
+    hipError_t e = dA.alloc(9);
+    if (e == hipSuccess) e = dW.alloc((size_t)num_views * 16);
+    if (e == hipSuccess) e = duv.alloc((size_t)MN * 2);
+    if (e == hipSuccess) e = dxy.alloc((size_t)MN * 2);
+    if (e == hipSuccess) e = dz.alloc((size_t)MN);
+    if (e == hipSuccess) e = dpv.alloc((size_t)MN);
+    if (e == hipSuccess) e = dpart.alloc((size_t)blocks * ns);
+    if (e == hipSuccess) e = hipMemcpy(dA.p, A, 72, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dW.p, W, (size_t)num_views * 128, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(duv.p, sensor_uv, (size_t)MN * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dxy.p, xy.data(), (size_t)MN * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dz.p, z.data(), (size_t)MN * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dpv.p, pv.data(), (size_t)MN * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        if (model == CALIB_MODEL_RADTAN)
+            hipLaunchKernelGGL((distortion_normal_kernel<kRadtan>), dim3(blocks), dim3(256), 0, 0, dA.p, dW.p, dpv.p,
+                               reinterpret_cast<const double2*>(duv.p), reinterpret_cast<const double2*>(dxy.p), dz.p, MN, dpart.p);
+        else
+            hipLaunchKernelGGL((distortion_normal_kernel<kFisheye>), dim3(blocks), dim3(256), 0, 0, dA.p, dW.p, dpv.p,
+                               reinterpret_cast<const double2*>(duv.p), reinterpret_cast<const double2*>(dxy.p), dz.p, MN, dpart.p);
+        e = hipGetLastError();
+    }
+    std::vector<double> part((size_t)blocks * ns);
+    if (e == hipSuccess) e = hipMemcpy(part.data(), dpart.p, part.size() * 8, hipMemcpyDeviceToHost);
+    dA.release(); dW.release(); duv.release(); dxy.release(); dz.release(); dpv.release(); dpart.release();
+    if (e != hipSuccess) return fail(CALIB_E_HIP, hipGetErrorString(e));
+    std::vector<double> sum((size_t)ns, 0.0);
+    for (int bidx = 0; bidx < blocks; ++bidx)
+        for (int j = 0; j < ns; ++j) sum[(size_t)j] += part[(size_t)bidx * ns + j];
+    int idx = 0;
+    for (int a2 = 0; a2 < nk; ++a2)
+        for (int b2 = a2; b2 < nk; ++b2) { out_DtD[a2 * nk + b2] = sum[(size_t)idx]; out_DtD[b2 * nk + a2] = sum[(size_t)idx]; ++idx; }
+    for (int a2 = 0; a2 < nk; ++a2) out_Dtd[a2] = sum[(size_t)idx++];
     return CALIB_OK;
 }
 

@@ -998,6 +998,204 @@ __global__ __launch_bounds__(256) void homography_lm_kernel(const int64_t* __res
     for (int j = 0; j < 9; ++j) if (i == j) H[view * 9 + j] = h[j] / h[8];       // Href /= Href[2,2]
 }
 
+// ---------------------------------------------------------------- closed-form initialisation (per view)
+// Normalised DLT homography (src/linearcalibrate.py:24-90), 16 lanes per view: centroid / mean
+// distance normalisation of sensor and model points, then the null vector of M (2N x 9). M^T M has
+// the block form [[S,0,-Su],[0,S,-Sv],[.,.,S(u^2+v^2)]] with S = sum p p^T, p = (X, Y, 1) (the same
+// structure as the homography LM above), and its smallest eigenvector -- the right singular vector the
+// reference takes from an SVD of M -- comes from 4 inverse iterations with the 16-lane solver.
+__global__ __launch_bounds__(256) void dlt_kernel(const int64_t* __restrict__ offs, const double2* __restrict__ uv,
+                                                  const double2* __restrict__ XY, int64_t M,
+                                                  double* __restrict__ H) {
+    const int tid = threadIdx.x, i = tid & 15;
+    const int64_t view = (int64_t)blockIdx.x * 16 + (tid >> 4);
+    if (view >= M) return;
+    const int64_t p0 = offs[view];
+    const int n = (int)(offs[view + 1] - p0);
+    double su = 0, sv = 0, sX = 0, sY = 0;
+    for (int q = i; q < n; q += 16) { const double2 m = uv[p0 + q], xy = XY[p0 + q]; su += m.x; sv += m.y; sX += xy.x; sY += xy.y; }
+    const double inv_n = 1.0 / (double)n;
+    const double mu = group_sum16(su) * inv_n, mv = group_sum16(sv) * inv_n;
+    const double mX = group_sum16(sX) * inv_n, mY = group_sum16(sY) * inv_n;
+    double da = 0, db = 0;
+    for (int q = i; q < n; q += 16) {
+        const double2 m = uv[p0 + q], xy = XY[p0 + q];
+        da += sqrt((m.x - mu) * (m.x - mu) + (m.y - mv) * (m.y - mv));
+        db += sqrt((xy.x - mX) * (xy.x - mX) + (xy.y - mY) * (xy.y - mY));
+    }
+    const double sa = 1.4142135623730951 / (group_sum16(da) * inv_n);
+    const double sb = 1.4142135623730951 / (group_sum16(db) * inv_n);
+    double S0[6] = {0, 0, 0, 0, 0, 0}, SU[6] = {0, 0, 0, 0, 0, 0}, SV[6] = {0, 0, 0, 0, 0, 0}, SE[6] = {0, 0, 0, 0, 0, 0};
+    for (int q = i; q < n; q += 16) {
+        const double2 m = uv[p0 + q], xy = XY[p0 + q];
+        const double u = sa * (m.x - mu), v = sa * (m.y - mv), X = sb * (xy.x - mX), Y = sb * (xy.y - mY);
+        const double a[6] = {X * X, X * Y, X, Y * Y, Y, 1.0};
+        const double e2 = u * u + v * v;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { S0[j] += a[j]; SU[j] += u * a[j]; SV[j] += v * a[j]; SE[j] += e2 * a[j]; }
+    }
+    double tr = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { S0[j] = group_sum16(S0[j]); SU[j] = group_sum16(SU[j]); SV[j] = group_sum16(SV[j]); SE[j] = group_sum16(SE[j]); }
+    tr = 2 * (S0[0] + S0[3] + S0[5]) + SE[0] + SE[3] + SE[5];
+    auto sym = [](const double (&S)[6], int r, int c) { const int lo = r < c ? r : c, hi = r < c ? c : r;
+                                                       return S[lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)]; };
+    double base[9];                        // row i of M^T M
+#pragma unroll
+    for (int c = 0; c < 9; ++c) base[c] = 0.0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        if (i == r) {
+            const int br = r / 3, rr = r % 3;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const int bc = c / 3, cc = c % 3;
+                double t = 0.0;
+                if (br == bc) t = br == 2 ? sym(SE, rr, cc) : sym(S0, rr, cc);
+                else if (br + bc == 2) t = -sym(SU, rr, cc);
+                else if (br + bc == 3) t = -sym(SV, rr, cc);
+                base[c] = t;
+            }
+        }
+    }
+    double x[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) x[c] = 1.0;
+    const double shift = 1e-15 * tr;       // keeps the solve finite when the data fit a homography exactly
+    for (int itn = 0; itn < 4; ++itn) {
+        double row[10];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) row[c] = base[c] + ((i == c) ? shift : 0.0);
+        double rhs = 0.0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) if (i == c) rhs = x[c];
+        row[9] = rhs;
+        int myCol;
+        double d;
+        (void)gauss_jordan16<9>(row, i, myCol, d);
+        double nrm = 0.0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) { x[c] = group_sum16(myCol == c ? d : 0.0); nrm = fmax(nrm, fabs(x[c])); }
+        const double inrm = 1.0 / nrm;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) x[c] *= inrm;
+    }
+    // H = Na^-1 Hp Nb with Na = [[sa,0,-sa mu],[0,sa,-sa mv],[0,0,1]], Nb likewise
+    double T[9];                            // Hp Nb
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        T[3 * r + 0] = x[3 * r + 0] * sb;
+        T[3 * r + 1] = x[3 * r + 1] * sb;
+        T[3 * r + 2] = x[3 * r + 2] - sb * (x[3 * r + 0] * mX + x[3 * r + 1] * mY);
+    }
+    double Hh[9];
+    const double isa = 1.0 / sa;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        Hh[c] = isa * T[c] + mu * T[6 + c];
+        Hh[3 + c] = isa * T[3 + c] + mv * T[6 + c];
+        Hh[6 + c] = T[6 + c];
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) if (i == j) H[view * 9 + j] = Hh[j] / Hh[8];
+}
+
+// Extrinsics from a homography and A^-1 (src/linearcalibrate.py:306-371): [r0 r1 t] = A^-1 H / |A^-1 h0|,
+// r2 = r0 x r1, then the nearest rotation. The reference takes U V^T from an SVD of Q = [r0 r1 r2];
+// that is the orthogonal polar factor of Q, reached here by Newton's iteration X <- (X + X^-T) / 2
+// (quadratic; Q is within a few percent of orthogonal, 8 steps are far past convergence).
+__global__ void extrinsics_kernel(const double* __restrict__ Ainv, const double* __restrict__ H, int64_t M,
+                                  double* __restrict__ W) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= M) return;
+    double Q[9], Ai[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) Ai[j] = Ainv[j];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            Q[3 * r + c] = Ai[3 * r] * H[v * 9 + c] + Ai[3 * r + 1] * H[v * 9 + 3 + c] + Ai[3 * r + 2] * H[v * 9 + 6 + c];
+    const double il = 1.0 / sqrt(Q[0] * Q[0] + Q[3] * Q[3] + Q[6] * Q[6]);
+    const double r0[3] = {Q[0] * il, Q[3] * il, Q[6] * il}, r1[3] = {Q[1] * il, Q[4] * il, Q[7] * il};
+    const double t[3] = {Q[2] * il, Q[5] * il, Q[8] * il};
+    double X[9] = {r0[0], r1[0], r0[1] * r1[2] - r0[2] * r1[1],
+                   r0[1], r1[1], r0[2] * r1[0] - r0[0] * r1[2],
+                   r0[2], r1[2], r0[0] * r1[1] - r0[1] * r1[0]};
+    for (int itn = 0; itn < 8; ++itn) {
+        // cofactor matrix C with X^-T = C / det
+        const double C[9] = {X[4] * X[8] - X[5] * X[7], X[5] * X[6] - X[3] * X[8], X[3] * X[7] - X[4] * X[6],
+                             X[2] * X[7] - X[1] * X[8], X[0] * X[8] - X[2] * X[6], X[1] * X[6] - X[0] * X[7],
+                             X[1] * X[5] - X[2] * X[4], X[2] * X[3] - X[0] * X[5], X[0] * X[4] - X[1] * X[3]};
+        const double idet = 1.0 / (X[0] * C[0] + X[1] * C[1] + X[2] * C[2]);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) X[j] = 0.5 * (X[j] + C[j] * idet);
+    }
+    double* o = W + v * 16;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { o[4 * r] = X[3 * r]; o[4 * r + 1] = X[3 * r + 1]; o[4 * r + 2] = X[3 * r + 2]; o[4 * r + 3] = t[r]; }
+    o[12] = 0.0; o[13] = 0.0; o[14] = 0.0; o[15] = 1.0;
+}
+
+// Normal equations of the linear distortion estimate D k = Ddot (src/distortion.py:110-191 radtan,
+// :222-271 fisheye, same row formulas): per workgroup partial of D^T D (upper triangle) and D^T Ddot,
+// summed on the host in block order and solved there (|k| <= 5 unknowns).
+template <int MODEL>
+__global__ __launch_bounds__(256) void distortion_normal_kernel(const double* __restrict__ A, const double* __restrict__ W,
+                                                                const int* __restrict__ pt_view,
+                                                                const double2* __restrict__ uv, const double2* __restrict__ XY,
+                                                                const double* __restrict__ Z, int64_t MN,
+                                                                double* __restrict__ part) {
+    constexpr int NK = ModelTraits<MODEL>::NK;
+    constexpr int NS = NK * (NK + 1) / 2 + NK;
+    __shared__ double sred[4][NS];
+    double acc[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) acc[j] = 0.0;
+    const double fx = A[0], sk = A[1], uc = A[2], fy = A[4], vc = A[5];
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < MN; p += (int64_t)gridDim.x * 256) {
+        const double* w = W + (int64_t)pt_view[p] * 16;
+        const double2 xy = XY[p], m = uv[p];
+        const double z = Z[p];
+        const double Xc = w[0] * xy.x + w[1] * xy.y + w[2] * z + w[3];
+        const double Yc = w[4] * xy.x + w[5] * xy.y + w[6] * z + w[7];
+        const double Zc = w[8] * xy.x + w[9] * xy.y + w[10] * z + w[11];
+        const double xn = Xc / Zc, yn = Yc / Zc, r2 = xn * xn + yn * yn;
+        const double u = fx * xn + sk * yn + uc, v = fy * yn + vc;
+        double du[NK], dv[NK];
+        if constexpr (MODEL == kRadtan) {
+            du[0] = (u - uc) * r2;            dv[0] = (v - vc) * r2;
+            du[1] = (u - uc) * r2 * r2;       dv[1] = (v - vc) * r2 * r2;
+            du[2] = fx * (2 * xn * yn);       dv[2] = fy * (r2 + 2 * yn * yn);
+            du[3] = fx * (r2 + 2 * xn * xn);  dv[3] = fy * (2 * xn * yn);
+            du[4] = (u - uc) * r2 * r2 * r2;  dv[4] = (v - vc) * r2 * r2 * r2;
+        } else {
+            const double r = sqrt(r2), th = atan(r), tr = th / r, t2 = th * th;
+            double pw = t2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { du[j] = fx * (u - uc) * tr * pw; dv[j] = fy * (v - vc) * tr * pw; pw *= t2; }
+        }
+        const double eu = m.x - u, ev = m.y - v;
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < NK; ++a)
+#pragma unroll
+            for (int b = a; b < NK; ++b) acc[idx++] += du[a] * du[b] + dv[a] * dv[b];
+#pragma unroll
+        for (int a = 0; a < NK; ++a) acc[idx++] += du[a] * eu + dv[a] * ev;
+    }
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        double t = acc[j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6][j] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < NS)
+        part[(int64_t)blockIdx.x * NS + threadIdx.x] = (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+}
+
 // ---------------------------------------------------------------- small forward-model kernels
 template <int MODEL>
 __global__ void distort_points_kernel(const double* __restrict__ xn, const double* __restrict__ k,

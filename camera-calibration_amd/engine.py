@@ -242,6 +242,50 @@ def refineHomographies(Hs, viewOffsets, sensorPoints, modelPoints, maxIters=20, 
     return H
 
 
+def _packedViews(viewOffsets, sensorPoints, modelPoints):
+    offs = np.ascontiguousarray(viewOffsets, dtype=np.int64)
+    s = np.ascontiguousarray(sensorPoints, dtype=np.float64).reshape(-1, 2)
+    m = np.ascontiguousarray(modelPoints, dtype=np.float64).reshape(-1, 3)
+    if s.shape[0] != offs[-1] or m.shape[0] != offs[-1]:
+        raise ValueError(f"Expected {int(offs[-1])} points, got {s.shape[0]} and {m.shape[0]}")
+    return offs, s, m
+
+
+def estimateHomographies(viewOffsets, sensorPoints, modelPoints, refineIters=20, device=0):
+    """Normalised DLT + LM polish of every view's homography on the device
+    (src/linearcalibrate.py:7-58, src/calibrate.py:60-111). -> (M,3,3), H[2,2] = 1."""
+    offs, s, m = _packedViews(viewOffsets, sensorPoints, modelPoints)
+    H = np.empty((offs.shape[0] - 1, 3, 3))
+    nat.requireDevice()
+    nat.check(nat.loadLibrary().calib_estimate_homographies(H.shape[0], nat.i64ptr(offs), nat.dptr(s), nat.dptr(m),
+                                                            nat.dptr(H), int(refineIters), int(device)))
+    return H
+
+
+def computeExtrinsics(Hs, A, device=0):
+    """World-to-camera poses (M,4,4) from homographies and A (src/linearcalibrate.py:306-371)."""
+    H = np.ascontiguousarray(np.asarray(Hs, dtype=np.float64).reshape(-1, 3, 3))
+    A = np.ascontiguousarray(A, dtype=np.float64).reshape(3, 3)
+    W = np.empty((H.shape[0], 4, 4))
+    nat.requireDevice()
+    nat.check(nat.loadLibrary().calib_compute_extrinsics(H.shape[0], nat.dptr(A), nat.dptr(H), nat.dptr(W), int(device)))
+    return W
+
+
+def distortionNormalEquations(modelId, viewOffsets, sensorPoints, modelPoints, A, W, device=0):
+    """D^T D and D^T Ddot of the linear distortion estimate (src/distortion.py:110-191, 222-271)."""
+    offs, s, m = _packedViews(viewOffsets, sensorPoints, modelPoints)
+    A = np.ascontiguousarray(A, dtype=np.float64).reshape(3, 3)
+    W = np.ascontiguousarray(np.asarray(W, dtype=np.float64).reshape(-1, 4, 4))
+    n = 5 if modelId == nat.MODEL_RADTAN else 4
+    G, g = np.empty((n, n)), np.empty(n)
+    nat.requireDevice()
+    nat.check(nat.loadLibrary().calib_distortion_normal_equations(modelId, offs.shape[0] - 1, nat.i64ptr(offs),
+                                                                  nat.dptr(s), nat.dptr(m), nat.dptr(A), nat.dptr(W),
+                                                                  nat.dptr(G), nat.dptr(g), int(device)))
+    return G, g
+
+
 def distortPoints(modelId, x, k):
     x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, 2)
     k = np.ascontiguousarray(k, dtype=np.float64).ravel()

@@ -242,6 +242,29 @@ def estimateDistortion(distortionModel, A, allDetections, allBoardPosesInCamera)
     return tuple(k.ravel())
 
 
+def solveDistortionNormalEquations(DtD, Dtd):
+    """k from D^T D k = D^T Ddot (what pinv(D) @ Ddot gives for a full-rank D); the columns of D span
+    many orders of magnitude (r^2 ... r^6), so the system is equilibrated before it is solved."""
+    DtD, Dtd = np.asarray(DtD, dtype=np.float64), np.asarray(Dtd, dtype=np.float64)
+    scale = 1.0 / np.sqrt(np.where(np.diagonal(DtD) > 0, np.diagonal(DtD), 1.0))
+    Gs = DtD * scale[:, None] * scale[None, :]
+    return tuple(scale * np.linalg.lstsq(Gs, scale * Dtd, rcond=None)[0])
+
+
+def estimateCalibrationParametersDevice(distortionModel, viewOffsets, sensorPoints, modelPoints, device=0):
+    """src/calibrate.py:41-58 with every per-view / per-point stage on the device (DLT + LM polish of
+    the homographies, extrinsics, the distortion normal equations); the 6-unknown intrinsics fit
+    and the <= 5-unknown distortion solve are host numpy. Packed (CSR) correspondences in,
+    (Ainitial, Winitial (M,4,4), kInitial) out."""
+    from . import engine
+    Hsref = engine.estimateHomographies(viewOffsets, sensorPoints, modelPoints, 20, device)
+    Ainitial = computeIntrinsicMatrix(Hsref)
+    Winitial = engine.computeExtrinsics(Hsref, Ainitial, device)
+    DtD, Dtd = engine.distortionNormalEquations(distortionModel.modelId, viewOffsets, sensorPoints, modelPoints,
+                                                Ainitial, Winitial, device)
+    return Ainitial, Winitial, solveDistortionNormalEquations(DtD, Dtd)
+
+
 def estimateCalibrationParameters(distortionModel, allDetections, refine=None):
     """src/calibrate.py:41-58 -> (Ainitial, Winitial, kInitial). `refine(Hs, allDetections)` polishes the
     homographies (default: the batched host implementation above; Calibrator passes the device kernel)."""

@@ -153,6 +153,22 @@ int calib_project_with_distortion(int model, int64_t n, const double* A, const d
 int calib_refine_homographies(int64_t num_views, const int64_t* view_offsets, const double* sensor_uv,
                               const double* model_xyz, double* H_inout, int max_iters, int device_id);
 
+/* ---- closed-form initialisation stage on the device (Calibrator.estimateCalibrationParameters,
+ * src/calibrate.py:41-58). The 6-unknown intrinsics fit and the <= 5-unknown distortion solve stay on
+ * the host; everything that is per view / per point runs here. ------------------------------------
+ * calib_estimate_homographies: normalised DLT (src/linearcalibrate.py:7-90) for every view, followed by
+ *   refine_iters LM iterations (0 = DLT only). H_out (M,3,3), H[2,2] = 1.
+ * calib_compute_extrinsics: world-to-camera poses from A (3,3) and the homographies
+ *   (src/linearcalibrate.py:306-371). W_out (M,4,4).
+ * calib_distortion_normal_equations: D^T D (n,n) and D^T Ddot (n) of the linear distortion estimate
+ *   D k = Ddot (src/distortion.py:110-191, 222-271), n = 5 radtan / 4 fisheye; W (M,4,4). */
+int calib_estimate_homographies(int64_t num_views, const int64_t* view_offsets, const double* sensor_uv,
+                                const double* model_xyz, double* H_out, int refine_iters, int device_id);
+int calib_compute_extrinsics(int64_t num_views, const double* A, const double* H, double* W_out, int device_id);
+int calib_distortion_normal_equations(int model, int64_t num_views, const int64_t* view_offsets,
+                                      const double* sensor_uv, const double* model_xyz, const double* A,
+                                      const double* W, double* out_DtD, double* out_Dtd, int device_id);
+
 /* HIP-event timing of the dominant kernels over the rounds enqueued since the last
  * calib_profile_enable(h, 1). which: 0 = jacobian kernel, 1 = J^T J (MFMA) kernel,
  * 2 = fused jacobian + J^T J kernel. */

@@ -355,3 +355,37 @@ def test_reference_unit_test_call_shapes():
     y = cal.projectAllPoints(P, [m for s, m in dets])
     assert y.shape[0] > 0 and y.shape[1] == 2
     assert cca.getSensorPoints(dets).shape == y.shape
+
+
+def test_device_initialisation_stages_vs_reference():
+    """DLT, extrinsics and the distortion normal equations on the device against the reference's
+    outputs (goldens g7, g2-g4) and the batched host implementation."""
+    from camera_calibration_amd import engine, linearcalibrate as lc
+    g7 = loadGolden("g7_homographies.npz")
+    for tag in ("u15", "c1"):
+        offs, s, m = g7[f"{tag}_viewOffsets"], g7[f"{tag}_sensorPoints"], g7[f"{tag}_modelPoints"]
+        H = engine.estimateHomographies(offs, s, m, refineIters=0)
+        # smallest eigenvector of M^T M by inverse iteration vs the reference's SVD of M
+        assert np.abs(H - g7[f"{tag}_H"]).max() <= 1e-8 * np.abs(g7[f"{tag}_H"]).max()
+        Hr = engine.estimateHomographies(offs, s, m, refineIters=20)
+        assert np.abs(Hr - g7[f"{tag}_Href"]).max() <= 1e-5
+    for tag, name in (("g2_config1_radtan.npz", "radtan"), ("g2_config1_fisheye.npz", "fisheye"),
+                      ("g3_unittest15.npz", "radtan"), ("g4_realistic.npz", "radtan")):
+        g = loadGolden(tag)
+        offs, s, m = g["viewOffsets"], g["sensorPoints"], g["modelPoints"]
+        model = cca.RadialTangentialModel() if name == "radtan" else cca.FisheyeModel()
+        # extrinsics: Newton polar iteration vs the reference's SVD projection, same A and H
+        dets = [(s[a:b], m[a:b]) for a, b in zip(offs[:-1], offs[1:])]
+        Hh = np.array(lc.refineHomographies(lc.estimateHomographies(dets), dets))
+        Wd = engine.computeExtrinsics(Hh, g["A0"])
+        Wh = np.array(lc.computeExtrinsics(Hh, g["A0"]))
+        assert np.abs(Wd - Wh).max() < 1e-12
+        assert np.abs(np.einsum("nij,nkj->nik", Wd[:, :3, :3], Wd[:, :3, :3]) - np.eye(3)).max() < 1e-14
+        # distortion: device normal equations + equilibrated solve vs the reference's pinv result
+        G, gg = engine.distortionNormalEquations(model.modelId, offs, s, m, g["A0"], g["W0"])
+        k = lc.solveDistortionNormalEquations(G, gg)
+        assert np.abs(np.array(k) - g["k0"]).max() <= 1e-7 * max(1.0, np.abs(g["k0"]).max())
+        # the whole stage
+        A, W, k = cca.Calibrator(model).estimateCalibrationParameters(dets)
+        assert np.abs(A - g["A0"]).max() < 1e-5 and np.abs(np.array(W) - g["W0"]).max() < 1e-6
+        assert np.abs(np.array(k) - g["k0"]).max() < 1e-5
