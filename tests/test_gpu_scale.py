@@ -255,3 +255,28 @@ def test_nan_candidate_is_rejected_not_propagated():
     assert np.all(trace[:, 4] == 0)                      # NaN < NaN is false: never accepted
     assert np.array_equal(P, sh["P0"])                   # parameters untouched
     eng.close()
+
+
+def test_whole_pipeline_at_scale_vs_c_oracle():
+    """30 000 views x 88 noisy points (2.64 M correspondences, 180 010 parameters): device initialisation
+    stage, then the LM loop from that (poor, strongly distorted) start against the C oracle's loop on
+    the same inputs: identical accept / lambda sequence, errors to 1e-11, parameters to 1e-8."""
+    from camera_calibration_amd import linearcalibrate as lc
+    from oracle import c_oracle
+    if not c_oracle.available():
+        pytest.skip("oracle/libcalib_oracle.so not built")
+    sh = synthetic.makeShard("c5", numViews=30000, noiseSigma=0.1)
+    offs, s, m = sh["viewOffsets"], sh["sensorPoints"], sh["modelPoints"]
+    A, W, k = lc.estimateCalibrationParametersDevice(cca.RadialTangentialModel(), offs, s, m)
+    assert np.isfinite(A).all() and np.isfinite(W).all() and np.isfinite(k).all()
+    P0 = synthetic.composeP(A, W, k)
+    eng = cca.RefineEngine("radtan")
+    eng.setProblem(offs, s, m)
+    sse, P, iters, tr = eng.refine(P0, 20)
+    sseO, PO, trO = c_oracle.refine(orc.RADTAN, P0, offs, s, m, 20)
+    n = min(iters, trO.shape[0])
+    assert n >= 10
+    assert np.array_equal(tr[:n, 3], trO[:n, 3]) and np.array_equal(tr[:n, 4], trO[:n, 4])
+    assert np.max(np.abs(tr[:n, 1] - trO[:n, 1]) / trO[:n, 1]) < 1e-11
+    assert np.abs(P - PO).max() < 1e-8
+    eng.close()
