@@ -175,7 +175,19 @@ def test_fp32_storage_path():
     sse64, P64, tr64 = orc.refineSchur(orc.RADTAN, P0, offs, s, m, 60)
     assert relIntr(P, P64, L) < 1e-6, relIntr(P, P64, L)
     assert relIntr(P, Ptrue, L) < 1e-6
+    # both LM modes evaluate the Jacobian in fp32 (the two kernels' code is contracted into FMAs
+    # differently, so values agree to ~1 fp32 ulp, not bitwise) and accumulate in fp64
+    B1, E1, V1, g1 = eng.normalEquations(P0)
     eng.close()
+    eng2 = cca.RefineEngine("radtan", "f32")
+    eng2.setProblem(offs, s, m)
+    eng2.setLmMode("two_kernel")
+    B2, E2, V2, g2 = eng2.normalEquations(P0)
+    for x, y in ((B1, B2), (E1, E2), (V1, V2), (g1, g2)):
+        assert np.abs(x - y).max() <= 1e-6 * np.abs(y).max()
+    sse2, P2, iters2, _ = eng2.refine(P0, 60)
+    assert relIntr(P2, P64, L) < 1e-6
+    eng2.close()
 
 
 def test_c5_shape_single_shard_sample():
