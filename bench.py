@@ -188,28 +188,31 @@ def main():
     fusedMs, fusedN = eng.profileRead(2)
     eng.profileEnable(False)
     sse, P, iters, trace = eng.lmEnd()
+    twoKernelMsPerStep = None
+    jacSteps = gramSteps = args.steps
     if rank == 0 and args.lm_mode == "fused":
         # the same shard through the two-kernel path (compact J through HBM), timed for the
-        # HBM roofline of the jacobian kernel and the gram kernel; not part of `value`
-        eng2 = cca.RefineEngine(cfg["model"], cfg["dtype"], local)
-        eng2.setProblem(shard["viewOffsets"], shard["sensorPoints"], shard["modelPoints"])
-        eng2.setLmMode("two_kernel")
-        eng2.lmBegin(shard["P0"], 16, **lmOpts)
-        eng2.lmRun(4)
-        eng2.lmDone()
-        eng2.profileEnable(True)
-        t2 = time.perf_counter()
-        eng2.lmRun(10)
-        eng2.lmDone()
-        twoKernelMsPerStep = (time.perf_counter() - t2) / 10 * 1e3
-        jacMs, jacN = eng2.profileRead(0)
-        gramMs, gramN = eng2.profileRead(1)
-        jacSteps = gramSteps = 10
-        eng2.lmEnd()
-        eng2.close()
-    else:
-        twoKernelMsPerStep = None
-        jacSteps = gramSteps = args.steps
+        # HBM roofline of the jacobian kernel and the gram kernel; not part of `value`, and not
+        # allowed to take the bench line down with it
+        try:
+            eng2 = cca.RefineEngine(cfg["model"], cfg["dtype"], local)
+            eng2.setProblem(shard["viewOffsets"], shard["sensorPoints"], shard["modelPoints"])
+            eng2.setLmMode("two_kernel")
+            eng2.lmBegin(shard["P0"], 16, **lmOpts)
+            eng2.lmRun(4)
+            eng2.lmDone()
+            eng2.profileEnable(True)
+            t2 = time.perf_counter()
+            eng2.lmRun(10)
+            eng2.lmDone()
+            twoKernelMsPerStep = (time.perf_counter() - t2) / 10 * 1e3
+            jacMs, jacN = eng2.profileRead(0)
+            gramMs, gramN = eng2.profileRead(1)
+            jacSteps = gramSteps = 10
+            eng2.lmEnd()
+            eng2.close()
+        except Exception as e:
+            print(f"bench: two-kernel pass skipped: {e}", file=sys.stderr)
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -299,7 +302,10 @@ def main():
             "setup_s": {"generate": tGen, "pack_upload": tUpload},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpuBaseline(shard, args.workload)
+            try:
+                out["cpu_baseline"] = cpuBaseline(shard, args.workload)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": str(e)}
         print(json.dumps(out))
     eng.close()
     if dist is not None:

@@ -308,7 +308,6 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
     const int item = blockIdx.x * (WAVES / wpi) + wave / wpi;
     const bool valid = item < n_items;
     const int c = lane & 15, k = lane >> 4;
-    const bool cvalid = c < C;
     T2* slab = reinterpret_cast<T2*>(smem) + wave * SLAB;
     T2* rslab = slab + ROWS * RS;
     d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -328,7 +327,6 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
         T z_n = Z[pn];
         for (int q0 = qbeg; q0 < qend; q0 += 64) {
             const int q = q0 + lane;
-            const bool pvalid = q < qend;
             const T2 m = m_n, xy = xy_n;
             const T z = z_n;
             if (q0 + 64 < qend) {
@@ -340,7 +338,6 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
             jacobian_point<MODEL, T>(sp, vc, xy.x, xy.y, z, u, v, Jc);
             // lanes past the item's end evaluate a clamped (finite) point; their rows are only ever
             // read as part of the last, partial 4-point group, where they are zeroed at the read
-            (void)pvalid;
             T2 res;
             res.x = m.x - u;
             res.y = m.y - v;
@@ -379,7 +376,6 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
         eacc += __shfl_xor(eacc, 16, 64);
         eacc += __shfl_xor(eacc, 32, 64);
     }
-    (void)cvalid;
     double* Gbase = sel ? ((st->cur ^ 1) ? G1 : G0) : G0;
     if (wpi == 1) {
         if (!valid) return;
