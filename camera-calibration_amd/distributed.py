@@ -88,3 +88,44 @@ def torchAllReduce(eng, device):
 
     allReduce.buffer = buf      # keep the storage alive
     return allReduce
+
+
+def refineDistributed(modelName, P0, viewOffsets, sensorPoints, modelPoints, maxIters, dtype="f64",
+                      checkEvery=8, engineFactory=None, allReduceFactory=None, **lmOptions):
+    """Refine ONE global problem with the views sharded over the ranks of the default
+    torch.distributed process group (every rank passes the same global arrays and gets the same
+    global result back). -> (sse, P (K,), iters, trace)
+
+    engineFactory(viewOffsets, sensor, model) / allReduceFactory(engine) exist so that the protocol
+    can be exercised without GPUs (tests); by default the shard engine is a RefineEngine on
+    cuda:LOCAL_RANK and the reduction a torch.distributed.all_reduce (RCCL) on its stream."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from . import engine as engine_mod
+    rank, world = dist.get_rank(), dist.get_world_size()
+    L = engine_mod.NUM_SHARED[engine_mod.MODEL_IDS[modelName]]
+    parts = partitionViews(viewOffsets, world)
+    Pl, ol, sl, ml = shardProblem(P0, viewOffsets, sensorPoints, modelPoints, L, parts[rank])
+    if engineFactory is None:
+        local = int(os.environ.get("LOCAL_RANK", rank))
+        eng = engine_mod.RefineEngine(modelName, dtype, local)
+        eng.setProblem(ol, sl, ml)
+        allReduce = torchAllReduce(eng, torch.device("cuda", local))
+    else:
+        eng = engineFactory(ol, sl, ml)
+        allReduce = allReduceFactory(eng)
+    lm = ShardedLM(eng, allReduce)
+    lm.begin(Pl, maxIters, **lmOptions)
+    lm.run(maxIters, checkEvery=checkEvery)
+    sse, Plocal, iters, trace = lm.end()
+    # assemble the global parameter vector: shared part is replicated, extrinsics are gathered
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (parts[rank], Plocal[L:]))
+    P = np.empty(L + 6 * (len(viewOffsets) - 1))
+    P[:L] = Plocal[:L]
+    for (v0, v1), ext in gathered:
+        P[L + 6 * v0:L + 6 * v1] = ext
+    if hasattr(eng, "close"):
+        eng.close()
+    return sse, P, iters, trace

@@ -104,3 +104,34 @@ def test_sharded_lm_matches_unsharded(tmp_path, world, tag, modelId):
     assert np.abs(P[:L] - g["Pfinal"][:L]).max() < 1e-9                 # the reference's own answer
     n = min(5, iters)
     assert np.array_equal(outs[0]["trace"][:n, 3], traceRef[:n, 3])
+
+
+def _workerGlobal(rank, world, port, outDir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = loadGolden("g3_unittest15.npz")
+
+        def allReduceFactory(eng):
+            buf = torch.from_numpy(eng.red)
+            return lambda: dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+
+        sse, P, iters, trace = distributed.refineDistributed(
+            "radtan", g["P0"], g["viewOffsets"], g["sensorPoints"], g["modelPoints"], 40,
+            engineFactory=lambda o, s, m: OracleShardEngine(orc.RADTAN, o, s, m), allReduceFactory=allReduceFactory)
+        np.savez(os.path.join(outDir, f"global{rank}.npz"), sse=sse, P=P, iters=iters)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_refine_distributed_returns_global_result(tmp_path):
+    """refineDistributed: every rank passes the global problem and receives the assembled global P."""
+    world = 2
+    mp.spawn(_workerGlobal, args=(world, _freePort(), str(tmp_path)), nprocs=world, join=True)
+    g = loadGolden("g3_unittest15.npz")
+    outs = [np.load(os.path.join(tmp_path, f"global{r}.npz")) for r in range(world)]
+    assert np.array_equal(outs[0]["P"], outs[1]["P"]) and outs[0]["P"].shape == g["P0"].shape
+    A, W, k = orc.decomposeParameterVector(outs[0]["P"], orc.RADTAN)
+    assert np.abs(A - g["Afinal"]).max() < 1e-9 and np.abs(k - g["kfinal"]).max() < 1e-9
+    assert np.abs(W - g["Wfinal"]).max() < 1e-8
