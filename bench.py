@@ -92,6 +92,12 @@ def cpuBaseline(shard, cfgName, seconds=20.0):
         "schur_form_value": n * iters / tSchur,
         "schur_form_note": f"same sample through the block-arrow/Schur numpy oracle, {tSchur:.2f} s",
         "c_openmp_port": cPort,
+        # quoted, not measured here: the reference itself in the survey container (BASELINE.md section 2,
+        # 8 vCPU Xeon 2.1 GHz, numpy 2.2.6 / sympy 1.14 through the import harness)
+        "reference_measured_in_survey": {
+            "config1_10x54_radtan": {"s_per_iter": 0.339, "point_residuals_per_s": 1.6e3},
+            "config2_scale_1000x54_radtan": {"s_per_iter": 510.0, "point_residuals_per_s": 105.0},
+            "configs3to5": "infeasible (dense J = 1.9 TB / 52 TB / 8.4 PB)"},
     }
 
 
