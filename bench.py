@@ -273,12 +273,14 @@ def main():
                         "mfma_flops_per_launch": mfmaFlops, "valu_fp64_flops_per_launch": valuFlops,
                         "mfma_only_frac": mfmaFlops / (fusedAvgMs * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
                         "points_per_launch": fusedPts,
-                        "algorithmic_hbm_bytes_per_launch": (5 * w + 4) * fusedPts,
+                        "algorithmic_hbm_bytes_per_launch": 5 * w * fusedPts,
                         "avg_launch_ms": fusedAvgMs, "launches_timed": fusedN}
         else:
             mainRoof = jacRoof
         out = {
-            "metric": "LM point-residuals/sec (and LM iters/sec), synthetic checkerboard, views sharded over GPUs",
+            "metric": "LM iters/sec & residuals/sec, 10k-view checkerboard @1/2/4/8 GPU",
+            "value_is": "point-residuals/s = points x LM iterations / wall time of the timed region "
+                        "(lm_iters_per_s beside it)",
             "value": MNglobal * args.steps / elapsed,
             "unit": "point-residuals/s",
             "lm_iters_per_s": args.steps / elapsed,
@@ -303,6 +305,8 @@ def main():
                               "points_per_launch": gramPts, "launches_per_step": gramN / gramSteps,
                               "avg_launch_ms": gramAvgMs, "launches_timed": gramN},
             "lm": {"accepted_steps_in_timed_region": accepted, "final_sse": sse,
+                   "note": "sensor noise makes the estimate differ from the generating parameters (statistical "
+                           "error); parity with the reference is asserted on noise-free data in tests/",
                    "max_rel_err_intrinsics_vs_truth": float(np.max(np.abs(P[:L] - shard["Ptrue"][:L])
                                                                    / np.maximum(np.abs(shard["Ptrue"][:L]), 1.0)))},
             "setup_s": {"generate": tGen, "pack_upload": tUpload},
