@@ -304,13 +304,20 @@ def main():
                               "mfma_util": gramFlops / (gramAvgMs * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS if gramN else None,
                               "points_per_launch": gramPts, "launches_per_step": gramN / gramSteps,
                               "avg_launch_ms": gramAvgMs, "launches_timed": gramN},
+            "valid": bool(iters == total),
             "lm": {"accepted_steps_in_timed_region": accepted, "final_sse": sse,
+                   "iterations_executed": int(iters), "iterations_requested": int(total),
                    "note": "sensor noise makes the estimate differ from the generating parameters (statistical "
                            "error); parity with the reference is asserted on noise-free data in tests/",
                    "max_rel_err_intrinsics_vs_truth": float(np.max(np.abs(P[:L] - shard["Ptrue"][:L])
                                                                    / np.maximum(np.abs(shard["Ptrue"][:L]), 1.0)))},
             "setup_s": {"generate": tGen, "pack_upload": tUpload},
         }
+        if iters != total:
+            # with the stop rule disabled lambda still overflows to inf after ~310 consecutive rejections
+            # (x10 each): the loop then ends early and later rounds are no-ops -- such a run is not a measurement
+            print(f"bench: only {iters} of {total} LM iterations executed (lambda left the fp64 range); "
+                  f"use fewer --steps", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpuBaseline(shard, args.workload)
