@@ -165,35 +165,56 @@ def main():
     tUpload = time.perf_counter() - t0
     eng.setLmMode(args.lm_mode)
     lmOpts = dict(lamInit=1e-3, lamMin=0.0, lamMax=float("inf"), errMin=-float("inf"))
-    total = args.warmup + args.steps
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
-        eng.lmDone()        # synchronises the engine's stream (its own stream when N == 1)
+        torch.cuda.synchronize()      # the engine's own stream was synchronised by the segment's lmEnd
 
+    # The LM loop runs in segments of at most SEG iterations; every segment is a fresh refinement of
+    # the same perturbed start point (lambda back at 1e-3, src/calibrate.py:142): with the stop rule
+    # disabled, lambda would otherwise overflow after ~310 consecutive rejections at the noise floor.
+    # A segment's bootstrap pass (one extra evaluation of all points) is inside the timed region but
+    # not counted as a step.
+    SEG = 100
     if dist is not None:
         allReduce = distributed.torchAllReduce(eng, torch.device("cuda", local))
         lm = distributed.ShardedLM(eng, allReduce)
-        lm.begin(shard["P0"], total, **lmOpts)
-        runRounds = lm.run
-    else:
-        eng.lmBegin(shard["P0"], total, **lmOpts)
-        eng.lmRun(1)
-        runRounds = eng.lmRun
-    runRounds(args.warmup)
+    state = {"P": shard["P0"], "iters": 0, "trace": [], "sse": float("nan")}
+
+    def runSteps(n):
+        done = 0
+        while done < n:
+            k = min(SEG, n - done)
+            if dist is not None:
+                lm.begin(shard["P0"], k, **lmOpts)
+                lm.run(k)
+            else:
+                eng.lmBegin(shard["P0"], k, **lmOpts)
+                eng.lmRun(k + 1)
+            done += k
+            sse_, P_, it_, tr_ = eng.lmEnd()          # synchronises
+            state["P"], state["sse"] = P_, sse_
+            state["iters"] += it_
+            state["trace"].append(tr_)
+
+    runSteps(args.warmup)
     barrier()
+    itersBefore = state["iters"]
+    state["trace"] = []
     eng.profileEnable(True)
     t0 = time.perf_counter()
-    runRounds(args.steps)
+    runSteps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     jacMs, jacN = eng.profileRead(0)
     gramMs, gramN = eng.profileRead(1)
     fusedMs, fusedN = eng.profileRead(2)
     eng.profileEnable(False)
-    sse, P, iters, trace = eng.lmEnd()
+    sse, P = state["sse"], state["P"]
+    iters = state["iters"] - itersBefore
+    trace = np.vstack(state["trace"]) if state["trace"] else np.zeros((0, 5 + eng.L))
+    total = args.steps
     twoKernelMsPerStep = None
     jacSteps = gramSteps = args.steps
     if rank == 0 and args.lm_mode == "fused":
@@ -243,7 +264,7 @@ def main():
         gramGBs = gramBytes * gramPts / (gramAvgMs * 1e-3) / 1e9 if gramN else None
         C = L + 6
         gramFlops = (4 * 16 * 16 + 4 * C) * gramPts      # as executed on full 16x16 MFMA tiles + J^T r
-        accepted = int(trace[args.warmup:, 4].sum()) if trace.shape[0] > args.warmup else 0
+        accepted = int(trace[:, 4].sum())
         pmc = {}
         trafficFile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(trafficFile):
@@ -260,11 +281,11 @@ def main():
                    "avg_launch_ms": jacAvgMs, "launches_timed": jacN}
         if fusedN:
             fusedAvgMs = fusedMs / fusedN
-            fusedPts = MNlocal * args.steps / fusedN
+            fusedPts = MNlocal
             mfmaFlops = 4 * 16 * 16 * fusedPts               # 2 x v_mfma_f64_16x16x4 (2048 flop) per 4 points
             # fp64 MFMA and fp64 VALU never co-execute on gfx950 (SQ_VALU_MFMA_COEXEC_CYCLES = 0, and
             # matrix peak = vector peak): both draw on the one 78.6 TFLOP/s fp64 budget
-            batches = viewsPerGpu * (-(-shard["pointsPerView"] // 64)) * args.steps / fusedN
+            batches = viewsPerGpu * (-(-shard["pointsPerView"] // 64))
             valuFlops = (FUSED_VALU_F64_FLOPS_PER_BATCH[cfg["model"]] * batches) if cfg["dtype"] == "f64" else 0.0
             tf = (mfmaFlops + valuFlops) / (fusedAvgMs * 1e-3) / 1e12
             mainRoof = {"kernel": "fused_kernel (jacobian blocks + v_mfma_f64_16x16x4_f64 J^T J, J on-chip)",
