@@ -104,7 +104,7 @@ def cpuBaseline(shard, cfgName, seconds=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", help="c2 | c3 | c4 | c5 (BASELINE.json configs[1..4])")
     ap.add_argument("--views", type=int, default=None, help="views per GPU (default: the config's)")
