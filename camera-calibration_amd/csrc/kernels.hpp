@@ -297,6 +297,7 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
     constexpr int RS = kFusedRowChunks;
     constexpr int SLAB = ROWS * RS + ROWS;                 // ROWS point rows + ROWS residual pairs
     constexpr int HALVES = 64 / ROWS;
+    constexpr bool RCOL = C < 16;                          // a free 16th MFMA column: J^T r and sum r^2 for free
     // one slab per wave; after the main loop the same memory holds the wave partial tiles
     __shared__ __attribute__((aligned(16))) unsigned char smem[WAVES * SLAB * sizeof(T2) > WAVES * kGStride * 8
                                                                      ? WAVES * SLAB * sizeof(T2) : WAVES * kGStride * 8];
@@ -349,8 +350,8 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
                     T2* row = slab + (lane & (ROWS - 1)) * RS;
 #pragma unroll
                     for (int cc = 0; cc < C; ++cc) row[cc] = Jc[cc];
-                    if (C < 16) { T2 t; t.x = T(0); t.y = T(0); row[15] = t; }
-                    rslab[lane & (ROWS - 1)] = res;
+                    if (RCOL) row[15] = res;                    // spare 16th column carries the residual
+                    else rslab[lane & (ROWS - 1)] = res;
                 }
                 __builtin_amdgcn_wave_barrier();
                 const int rows = qend - (q0 + ROWS * half);     // valid points in this pass (may exceed ROWS)
@@ -358,40 +359,53 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
                 for (int s = 0; s < ROWS / 4; ++s) {
                     if (4 * s >= rows) break;                   // wave-uniform
                     const T2 jv = slab[(4 * s + k) * RS + c];
-                    const T2 rv = rslab[4 * s + k];
                     double jx = (double)jv.x, jy = (double)jv.y;
-                    double rx = (double)rv.x, ry = (double)rv.y;
-                    if (4 * s + 4 > rows && 4 * s + k >= rows) {        // partial last group (outer test wave-uniform)
-                        jx = 0.0; jy = 0.0; rx = 0.0; ry = 0.0;
-                    }
+                    const bool dead = 4 * s + 4 > rows && 4 * s + k >= rows;   // partial last group (outer test wave-uniform)
+                    if (dead) { jx = 0.0; jy = 0.0; }
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jx, jx, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc, 0, 0, 0);
-                    gacc += jx * rx + jy * ry;
-                    eacc += rx * rx + ry * ry;
+                    if (!RCOL) {
+                        const T2 rv = rslab[4 * s + k];
+                        const double rx = dead ? 0.0 : (double)rv.x, ry = dead ? 0.0 : (double)rv.y;
+                        gacc += jx * rx + jy * ry;
+                        eacc += rx * rx + ry * ry;
+                    }
                 }
             }
         }
-        gacc += __shfl_xor(gacc, 16, 64);
-        gacc += __shfl_xor(gacc, 32, 64);
-        eacc += __shfl_xor(eacc, 16, 64);
-        eacc += __shfl_xor(eacc, 32, 64);
+        if (!RCOL) {
+            gacc += __shfl_xor(gacc, 16, 64);
+            gacc += __shfl_xor(gacc, 32, 64);
+            eacc += __shfl_xor(eacc, 16, 64);
+            eacc += __shfl_xor(eacc, 32, 64);
+        }
     }
+    // tile (f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg), J^T r, sum r^2 -> dst[0..272].
+    // With the residual in column 15 the tile's last row is J^T r and its corner sum r^2; row and
+    // column 15 of the stored tile are zero either way (what the elimination kernels expect).
+    auto emit = [&](double* dst) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = k + 4 * reg;
+            dst[row * 16 + c] = (RCOL && (c == 15 || row == 15)) ? 0.0 : acc[reg];
+        }
+        if (RCOL) {
+            if (k == 3) dst[c == 15 ? 272 : 256 + c] = acc[3];  // lanes of row 15: J^T r (c < 15), sum r^2 (c = 15)
+            if (k == 0 && c == 15) dst[256 + 15] = 0.0;
+        } else {
+            if (k == 0) dst[256 + c] = gacc;
+            if (lane == 0) dst[272] = eacc;
+        }
+    };
     double* Gbase = sel ? ((st->cur ^ 1) ? G1 : G0) : G0;
     if (wpi == 1) {
         if (!valid) return;
-        double* G = Gbase + (int64_t)item * kGStride;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) G[(k + 4 * reg) * 16 + c] = acc[reg];
-        if (k == 0) G[256 + c] = gacc;
-        if (lane == 0) G[272] = eacc;
+        emit(Gbase + (int64_t)item * kGStride);
         return;
     }
     __syncthreads();                                            // slabs are dead, reuse as partial tiles
     double* sred = reinterpret_cast<double*>(smem);
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) sred[wave * kGStride + (k + 4 * reg) * 16 + c] = acc[reg];
-    if (k == 0) sred[wave * kGStride + 256 + c] = gacc;
-    if (lane == 0) sred[wave * kGStride + 272] = eacc;
+    emit(sred + wave * kGStride);
     __syncthreads();
     if (sub == 0 && valid) {
         double* G = Gbase + (int64_t)item * kGStride;
