@@ -295,9 +295,14 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
     using T2 = typename Pair<T>::type;
     constexpr int C = ModelTraits<MODEL>::C;
     constexpr int RS = kFusedRowChunks;
-    constexpr int SLAB = ROWS * RS + ROWS;                 // ROWS point rows + ROWS residual pairs
+    constexpr int SLAB = ROWS * RS;                        // ROWS point rows of 16 (du, dv) chunks + 1 pad chunk
     constexpr int HALVES = 64 / ROWS;
     constexpr bool RCOL = C < 16;                          // a free 16th MFMA column: J^T r and sum r^2 for free
+    // C == 16 (radial-tangential): columns 3 and 4 of J are the constants (1,0) and (0,1). With the u rows
+    // and the v rows accumulated in separate tiles, column 3 can carry (1,1) -- tile_u[.][3] = sum Ju,
+    // tile_v[.][3] = sum Jv, i.e. what columns 3 and 4 used to give -- and column 4 the residual
+    // (ru, rv): (tile_u + tile_v)[.][4] = J^T r, [4][4] = sum r^2, tile_u[3][4] = sum ru, tile_v[3][4] = sum rv.
+    constexpr bool ONES = !RCOL;
     // one slab per wave; after the main loop the same memory holds the wave partial tiles
     __shared__ __attribute__((aligned(16))) unsigned char smem[WAVES * SLAB * sizeof(T2) > WAVES * kGStride * 8
                                                                      ? WAVES * SLAB * sizeof(T2) : WAVES * kGStride * 8];
@@ -310,9 +315,7 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
     const bool valid = item < n_items;
     const int c = lane & 15, k = lane >> 4;
     T2* slab = reinterpret_cast<T2*>(smem) + wave * SLAB;
-    T2* rslab = slab + ROWS * RS;
-    d4 acc = {0.0, 0.0, 0.0, 0.0};
-    double gacc = 0.0, eacc = 0.0;
+    d4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
     if (valid) {
         const int64_t pbeg = item_pt0[item];
         const int n = item_n[item];
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
 #pragma unroll
                     for (int cc = 0; cc < C; ++cc) row[cc] = Jc[cc];
                     if (RCOL) row[15] = res;                    // spare 16th column carries the residual
-                    else rslab[lane & (ROWS - 1)] = res;
+                    if (ONES) { T2 one; one.x = T(1); one.y = T(1); row[3] = one; row[4] = res; }
                 }
                 __builtin_amdgcn_wave_barrier();
                 const int rows = qend - (q0 + ROWS * half);     // valid points in this pass (may exceed ROWS)
@@ -363,38 +366,38 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
                     const bool dead = 4 * s + 4 > rows && 4 * s + k >= rows;   // partial last group (outer test wave-uniform)
                     if (dead) { jx = 0.0; jy = 0.0; }
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jx, jx, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc, 0, 0, 0);
-                    if (!RCOL) {
-                        const T2 rv = rslab[4 * s + k];
-                        const double rx = dead ? 0.0 : (double)rv.x, ry = dead ? 0.0 : (double)rv.y;
-                        gacc += jx * rx + jy * ry;
-                        eacc += rx * rx + ry * ry;
-                    }
+                    if (ONES) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc2, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc, 0, 0, 0);
                 }
             }
-        }
-        if (!RCOL) {
-            gacc += __shfl_xor(gacc, 16, 64);
-            gacc += __shfl_xor(gacc, 32, 64);
-            eacc += __shfl_xor(eacc, 16, 64);
-            eacc += __shfl_xor(eacc, 32, 64);
         }
     }
     // tile (f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg), J^T r, sum r^2 -> dst[0..272].
     // With the residual in column 15 the tile's last row is J^T r and its corner sum r^2; row and
     // column 15 of the stored tile are zero either way (what the elimination kernels expect).
     auto emit = [&](double* dst) {
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int row = k + 4 * reg;
-            dst[row * 16 + c] = (RCOL && (c == 15 || row == 15)) ? 0.0 : acc[reg];
-        }
         if (RCOL) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = k + 4 * reg;
+                dst[row * 16 + c] = (c == 15 || row == 15) ? 0.0 : acc[reg];
+            }
             if (k == 3) dst[c == 15 ? 272 : 256 + c] = acc[3];  // lanes of row 15: J^T r (c < 15), sum r^2 (c = 15)
             if (k == 0 && c == 15) dst[256 + 15] = 0.0;
         } else {
-            if (k == 0) dst[256 + c] = gacc;
-            if (lane == 0) dst[272] = eacc;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = k + 4 * reg;
+                const double U = acc[reg], V = acc2[reg];
+                const bool rs = row == 3 || row == 4, cs = c == 3 || c == 4;
+                if (!rs && !cs) dst[row * 16 + c] = U + V;
+                else if (!rs && c == 3) { dst[row * 16 + 3] = U; dst[row * 16 + 4] = V; }     // sum Ju[row], sum Jv[row]
+                else if (!rs && c == 4) dst[256 + row] = U + V;                                // J^T r
+                else if (row == 3 && !cs) { dst[3 * 16 + c] = U; dst[4 * 16 + c] = V; }
+                else if (row == 3 && c == 3) { dst[3 * 16 + 3] = U; dst[4 * 16 + 4] = V; dst[3 * 16 + 4] = 0.0; dst[4 * 16 + 3] = 0.0; }
+                else if (row == 3 && c == 4) { dst[256 + 3] = U; dst[256 + 4] = V; }           // sum ru, sum rv
+                else if (row == 4 && c == 4) dst[272] = U + V;                                 // sum r^2
+            }
         }
     };
     double* Gbase = sel ? ((st->cur ^ 1) ? G1 : G0) : G0;
