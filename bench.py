@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MATRIX_PEAK_TFLOPS = 78.6  # public MI355X sheet; fp64 MFMA = fp64 vector rate
 # fp64 VALU flops the fused kernel executes per 64-point wave batch (all 64 lanes counted), from
 # rocprofv3 --pmc SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 (profiles/README.md): 64 x (2 FMA + MUL + ADD + TRANS)
-FUSED_VALU_F64_FLOPS_PER_BATCH = {"fisheye": 23.8e3, "radtan": 17.4e3}
+FUSED_VALU_F64_FLOPS_PER_BATCH = {"fisheye": 17.3e3, "radtan": 11.9e3}
 
 
 def algorithmicBytesPerPoint(L, wordBytes):
