@@ -325,6 +325,15 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
         const T* vc = VC + (int64_t)__builtin_amdgcn_readfirstlane(item_view[item]) * kViewStride;
         Shared<MODEL, T> sp;
         sp.load(P);
+        // the constant columns of the slab rows: d(u,v)/duc = (1,0), d(u,v)/dvc = (0,1); for C == 16
+        // column 3 holds (1,1) and column 4 is rewritten with the residual per batch (ONES, above)
+        if (lane < ROWS) {
+            T2 c3, c4;
+            c3.x = T(1); c3.y = ONES ? T(1) : T(0);
+            c4.x = T(0); c4.y = T(1);
+            slab[lane * RS + 3] = c3;
+            if (!ONES) slab[lane * RS + 4] = c4;
+        }
         // inputs of the next batch are requested before the current batch is evaluated
         int64_t pn = pbeg + (qbeg + lane < qend ? qbeg + lane : qend - 1);
         T2 m_n = uv[pn], xy_n = XY[pn];
@@ -352,9 +361,10 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
                 if (HALVES == 1 || (lane >> 5) == half) {
                     T2* row = slab + (lane & (ROWS - 1)) * RS;
 #pragma unroll
-                    for (int cc = 0; cc < C; ++cc) row[cc] = Jc[cc];
+                    for (int cc = 0; cc < C; ++cc)
+                        if (cc != 3 && cc != 4) row[cc] = Jc[cc];       // columns 3, 4 are constants, set once above
                     if (RCOL) row[15] = res;                    // spare 16th column carries the residual
-                    if (ONES) { T2 one; one.x = T(1); one.y = T(1); row[3] = one; row[4] = res; }
+                    if (ONES) row[4] = res;
                 }
                 __builtin_amdgcn_wave_barrier();
                 const int rows = qend - (q0 + ROWS * half);     // valid points in this pass (may exceed ROWS)
