@@ -219,16 +219,19 @@ int launch_fused(calib_handle_s* h, const LMState* st, int sel) {
                                           : launch_fused_t<kFisheye, float>(h, st, sel);
 }
 
+// per-view kernels skip the view -> item indirection when every view is a single item
+const int* view_items(const calib_handle_s* h) { return h->n_items == h->nv ? nullptr : h->view_item0.p; }
+
 int launch_schur_reduce(calib_handle_s* h, const LMState* st, double* red) {
     const int VA = variantSize(h->L);
     if (h->nv > 0) {
-        dim3 grid(h->schur_blocks, 2);
+        dim3 grid(h->schur_blocks, 3);
         if (h->L == 10)
             hipLaunchKernelGGL((schur_kernel<10>), grid, dim3(kSchurBlock), 0, h->stream, h->G[0].p,
-                               h->G[1].p, st, h->view_item0.p, h->nv, h->part.p);
+                               h->G[1].p, st, view_items(h), h->nv, h->n_items, h->part.p);
         else
             hipLaunchKernelGGL((schur_kernel<9>), grid, dim3(kSchurBlock), 0, h->stream, h->G[0].p,
-                               h->G[1].p, st, h->view_item0.p, h->nv, h->part.p);
+                               h->G[1].p, st, view_items(h), h->nv, h->n_items, h->part.p);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(reduce_kernel, dim3(2 * VA), dim3(64), 0, h->stream, h->part.p,
@@ -247,7 +250,7 @@ int launch_update_backsub_t(calib_handle_s* h) {
     const int per = kSchurThreads / 16;
     const int blocks = std::max(1, std::min(2048, (h->nv + per - 1) / per));     // grid-stride over views
     hipLaunchKernelGGL((update_backsub_kernel<L, T>), dim3(blocks), dim3(kSchurThreads), 0, h->stream, h->G[0].p,
-                       h->G[1].p, st_cur(h), st_next(h), h->red, h->view_item0.p, h->view_ext.p, h->nv,
+                       h->G[1].p, st_cur(h), st_next(h), h->red, view_items(h), h->view_ext.p, h->nv,
                        h->P[0].p, h->P[1].p, h->trace.p, reinterpret_cast<T*>(h->VC.p));
     HIP_TRY(hipGetLastError());
     return CALIB_OK;
@@ -757,11 +760,11 @@ int calib_normal_eq(calib_handle_t h, const double* P, double* out_B, double* ou
             for (int it = vi0[v]; it < vi0[v + 1]; ++it)
                 for (int i = 0; i < kGStride; ++i) blk[i] += G[(size_t)it * kGStride + i];
             for (int a = 0; a < 6; ++a) {
-                if (out_g) out_g[L + 6 * (int64_t)v + a] = blk[256 + L + a];
+                if (out_g) out_g[L + 6 * (int64_t)v + a] = blk[kGg + L + a];
                 for (int b = 0; b < 6; ++b)
-                    if (out_V) out_V[((int64_t)v * 6 + a) * 6 + b] = blk[(L + a) * 16 + L + b];
+                    if (out_V) out_V[((int64_t)v * 6 + a) * 6 + b] = blk[kGRows + a * 16 + L + b];
                 for (int c = 0; c < L; ++c)
-                    if (out_E) out_E[((int64_t)v * L + c) * 6 + a] = blk[c * 16 + L + a];
+                    if (out_E) out_E[((int64_t)v * L + c) * 6 + a] = blk[kGRows + a * 16 + c];
             }
         }
     }

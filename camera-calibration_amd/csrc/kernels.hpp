@@ -18,8 +18,32 @@ namespace calib {
 constexpr int kTile = 256;        // points per jacobian workgroup
 constexpr int kGramChunk = 512;   // points per gram work item (one wave)
 constexpr int kGramUnroll = 4;    // 4-point groups (1 KiB wave-loads of J) in flight per trip
-constexpr int kGStride = 288;     // doubles per item: G 16x16, g 16, [272] = sum r^2 (rest pad)
+// Per-item normal-equation record. With the parameter order (L shared, 6 view) the 16x16 tile
+// G = J^T J splits into B = G[0:L, 0:L] and the six view rows R = G[L:L+6, 0:16] = [E^T | V | 0]; the
+// record keeps R first, then g = J^T r and sum r^2, then B, so the kernels that only eliminate the
+// view block (variant B of schur_kernel, update_backsub_kernel) read the leading kGHead doubles.
+constexpr int kGRows = 0;         // R[m][c] at m * 16 + c
+constexpr int kGg = 96;           // g[c]
+constexpr int kGSse = 112;        // sum r^2
+constexpr int kGHead = 113;
+constexpr int kGB = 120;          // B[r][c] at kGB + r * L + c
+constexpr int kGStride = 224;     // doubles per item (1792 B)
 constexpr int kMaxL = 10;
+
+// slot of tile entry (row, col) in the record, -1 when the entry is not kept (the E block above the
+// diagonal is the transpose of R's leading columns; row / column 15 of a 15-column model is zero)
+template <int L>
+__device__ __forceinline__ int gSlot(int row, int col) {
+    if (row >= L && row < L + 6) return kGRows + (row - L) * 16 + col;
+    if (row < L && col < L) return kGB + row * L + col;
+    return -1;
+}
+template <int L>
+__device__ __forceinline__ void gPut(double* dst, int row, int col, double val) {
+    const int s = gSlot<L>(row, col);
+    if (s >= 0) dst[s] = val;
+}
+__device__ __forceinline__ bool gLive(int i, int L) { return i < kGHead || (i >= kGB && i < kGB + L * L); }
 
 // Compact Jacobian in HBM: groups of 4 points, [group][column][point-in-group] of (du, dv) pairs.
 // The jacobian kernel's store of one column then writes 64 B per 4 lanes (instead of 16 B per
@@ -251,19 +275,20 @@ __global__ __launch_bounds__(256) void gram_kernel(const typename Pair<T>::type*
         if (!valid) return;
         double* G = Gbase + (int64_t)item * kGStride;
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) G[(k + 4 * reg) * 16 + c] = acc[reg];
-        if (k == 0) G[256 + c] = gacc;
-        if (lane == 0) G[272] = eacc;           // sum over the item's points of |r|^2
+        for (int reg = 0; reg < 4; ++reg) gPut<C - 6>(G, k + 4 * reg, c, acc[reg]);
+        if (k == 0) G[kGg + c] = gacc;
+        if (lane == 0) G[kGSse] = eacc;         // sum over the item's points of |r|^2
         return;
     }
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) sred[wave][(k + 4 * reg) * 16 + c] = acc[reg];
-    if (k == 0) sred[wave][256 + c] = gacc;
-    if (lane == 0) sred[wave][272] = eacc;
+    for (int reg = 0; reg < 4; ++reg) gPut<C - 6>(sred[wave], k + 4 * reg, c, acc[reg]);
+    if (k == 0) sred[wave][kGg + c] = gacc;
+    if (lane == 0) sred[wave][kGSse] = eacc;
     __syncthreads();
     if (sub == 0 && valid) {                    // the item's first wave sums the partials in wave order
         double* G = Gbase + (int64_t)item * kGStride;
-        for (int i = lane; i < 273; i += 64) {
+        for (int i = lane; i < kGStride; i += 64) {
+            if (!gLive(i, C - 6)) continue;
             double t = sred[wave][i];
             for (int w = 1; w < wpi; ++w) t += sred[wave + w][i];
             G[i] = t;
@@ -382,31 +407,32 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
             }
         }
     }
-    // tile (f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg), J^T r, sum r^2 -> dst[0..272].
-    // With the residual in column 15 the tile's last row is J^T r and its corner sum r^2; row and
-    // column 15 of the stored tile are zero either way (what the elimination kernels expect).
+    // tile (f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg), J^T r, sum r^2 -> record at dst.
+    // With the residual in column 15 the tile's last row is J^T r and its corner sum r^2; column 15 of
+    // the stored view rows is zero either way (what the elimination kernels expect).
+    constexpr int L = C - 6;
     auto emit = [&](double* dst) {
         if (RCOL) {
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int row = k + 4 * reg;
-                dst[row * 16 + c] = (c == 15 || row == 15) ? 0.0 : acc[reg];
+                gPut<L>(dst, row, c, (c == 15 || row == 15) ? 0.0 : acc[reg]);
             }
-            if (k == 3) dst[c == 15 ? 272 : 256 + c] = acc[3];  // lanes of row 15: J^T r (c < 15), sum r^2 (c = 15)
-            if (k == 0 && c == 15) dst[256 + 15] = 0.0;
+            if (k == 3) dst[c == 15 ? kGSse : kGg + c] = acc[3];  // lanes of row 15: J^T r (c < 15), sum r^2 (c = 15)
+            if (k == 0 && c == 15) dst[kGg + 15] = 0.0;
         } else {
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int row = k + 4 * reg;
                 const double U = acc[reg], V = acc2[reg];
                 const bool rs = row == 3 || row == 4, cs = c == 3 || c == 4;
-                if (!rs && !cs) dst[row * 16 + c] = U + V;
-                else if (!rs && c == 3) { dst[row * 16 + 3] = U; dst[row * 16 + 4] = V; }     // sum Ju[row], sum Jv[row]
-                else if (!rs && c == 4) dst[256 + row] = U + V;                                // J^T r
-                else if (row == 3 && !cs) { dst[3 * 16 + c] = U; dst[4 * 16 + c] = V; }
-                else if (row == 3 && c == 3) { dst[3 * 16 + 3] = U; dst[4 * 16 + 4] = V; dst[3 * 16 + 4] = 0.0; dst[4 * 16 + 3] = 0.0; }
-                else if (row == 3 && c == 4) { dst[256 + 3] = U; dst[256 + 4] = V; }           // sum ru, sum rv
-                else if (row == 4 && c == 4) dst[272] = U + V;                                 // sum r^2
+                if (!rs && !cs) gPut<L>(dst, row, c, U + V);
+                else if (!rs && c == 3) { gPut<L>(dst, row, 3, U); gPut<L>(dst, row, 4, V); }     // sum Ju[row], sum Jv[row]
+                else if (!rs && c == 4) dst[kGg + row] = U + V;                                    // J^T r
+                else if (row == 3 && !cs) { gPut<L>(dst, 3, c, U); gPut<L>(dst, 4, c, V); }
+                else if (row == 3 && c == 3) { gPut<L>(dst, 3, 3, U); gPut<L>(dst, 4, 4, V); gPut<L>(dst, 3, 4, 0.0); gPut<L>(dst, 4, 3, 0.0); }
+                else if (row == 3 && c == 4) { dst[kGg + 3] = U; dst[kGg + 4] = V; }               // sum ru, sum rv
+                else if (row == 4 && c == 4) dst[kGSse] = U + V;                                   // sum r^2
             }
         }
     };
@@ -422,7 +448,8 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
     __syncthreads();
     if (sub == 0 && valid) {
         double* G = Gbase + (int64_t)item * kGStride;
-        for (int i = lane; i < 273; i += 64) {
+        for (int i = lane; i < kGStride; i += 64) {
+            if (!gLive(i, L)) continue;
             double t = sred[wave * kGStride + i];
             for (int w = 1; w < wpi; ++w) t += sred[(wave + w) * kGStride + i];
             G[i] = t;
@@ -434,38 +461,47 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
 // 16 lanes per view; lane c owns column c of the view's symmetric 16x16 Gram.
 __device__ __forceinline__ constexpr int tri(int m, int n) { return m * (m + 1) / 2 + n; }
 
+// 1/sqrt(d) for the Cholesky pivots: v_rsq_f64 seed (~2^-26 relative) and two Newton steps -- a
+// chain of 9 dependent operations instead of the ~40 of sqrt() followed by a division
+__device__ __forceinline__ double rsqrt_nr(double d) {
+    double r = __builtin_amdgcn_rsq(d);
+    r = r * (1.5 - 0.5 * d * r * r);
+    r = r * (1.5 - 0.5 * d * r * r);
+    return r;
+}
+
 template <int L>
 struct Elim {
-    double Lc[21];    // Cholesky factor of V + lam diag(V) (lower, off-diagonals)
+    double Lc[21];    // Cholesky factor of V + lam diag(V) (strictly lower part; diagonal slots unused)
     double invd[6];   // 1 / diagonal of the factor
     double z[6];      // Lc^-1 (this lane's column restricted to the view rows)
     double zg[6];     // Lc^-1 g_view
     bool fail;
 };
 
-__device__ __forceinline__ void load_view_col(const double* __restrict__ G, int item0, int nitems,
-                                              int c, double (&col)[16], double& gc, double& sse) {
+// this lane's column of the view rows R (b[m] = R[m][c]) and of g, summed over the view's items
+__device__ __forceinline__ void load_view_rows(const double* __restrict__ G, int item0, int nitems,
+                                               int c, double (&b)[6], double& gc) {
+    const double* g = G + (int64_t)item0 * kGStride;
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) col[rr] = 0.0;
-    gc = 0.0;
-    sse = 0.0;
-    for (int it = 0; it < nitems; ++it) {
-        const double* g = G + (int64_t)(item0 + it) * kGStride;
+    for (int m = 0; m < 6; ++m) b[m] = g[kGRows + m * 16 + c];
+    gc = g[kGg + c];
+    for (int it = 1; it < nitems; ++it) {                     // > 1 item only for views above kGramChunk points
+        g += kGStride;
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) col[rr] += g[rr * 16 + c];
-        gc += g[256 + c];
-        sse += g[272];
+        for (int m = 0; m < 6; ++m) b[m] += g[kGRows + m * 16 + c];
+        gc += g[kGg + c];
     }
 }
 
 template <int L>
-__device__ __forceinline__ void eliminate(const double (&col)[16], double gc, double lam,
+__device__ __forceinline__ void eliminate(const double (&b)[6], double gc, double lam,
                                           Elim<L>& e) {
     double V[21];
 #pragma unroll
     for (int m = 0; m < 6; ++m)
 #pragma unroll
-        for (int n = 0; n <= m; ++n) V[tri(m, n)] = __shfl(col[L + m], L + n, 16);
+        for (int n = 0; n <= m; ++n) V[tri(m, n)] = __shfl(b[m], L + n, 16);
     double gv[6];
 #pragma unroll
     for (int m = 0; m < 6; ++m) gv[m] = __shfl(gc, L + m, 16);
@@ -476,10 +512,8 @@ __device__ __forceinline__ void eliminate(const double (&col)[16], double gc, do
 #pragma unroll
         for (int q = 0; q < j; ++q) d -= e.Lc[tri(j, q)] * e.Lc[tri(j, q)];
         if (!(d > 0.0)) e.fail = true;
-        const double ljj = sqrt(d);
-        const double inv = 1.0 / ljj;
+        const double inv = rsqrt_nr(d);
         e.invd[j] = inv;
-        e.Lc[tri(j, j)] = ljj;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             double t = V[tri(i, j)];
@@ -490,7 +524,7 @@ __device__ __forceinline__ void eliminate(const double (&col)[16], double gc, do
     }
 #pragma unroll
     for (int m = 0; m < 6; ++m) {
-        double t = col[L + m], tg = gv[m];
+        double t = b[m], tg = gv[m];
 #pragma unroll
         for (int n = 0; n < m; ++n) { t -= e.Lc[tri(m, n)] * e.z[n]; tg -= e.Lc[tri(m, n)] * e.zg[n]; }
         e.z[m] = t * e.invd[m];
@@ -499,13 +533,14 @@ __device__ __forceinline__ void eliminate(const double (&col)[16], double gc, do
 }
 
 // ---------------------------------------------------------------- schur partials
-// grid (nblocks, 2): y = 0 variant A (candidate blocks, lambda_accept),
-//                    y = 1 variant B (current blocks, lambda_reject).
-// 16 lanes per view, 4 views per wave and trip. Every lane factors the view's damped 6x6 block
-// Vh = Lc Lc^T (loaded by broadcast), lane c < L forward-substitutes its row of E (z_c = Lc^-1 E_c),
-// lane L the view gradient (z_g = Lc^-1 g_v). Then sum_views E Vh^-1 [E^T | g_v] = W^T W with
-// W = [z_0 .. z_{L-1} z_g] is one more tall-skinny Gram: 6 x v_mfma_f64_16x16x4_f64 per trip,
-// K-slot = view, no cross-lane traffic. B, g_c, sum r^2 are plain per-lane sums (variant A only).
+// grid (nblocks, 3): y = 0 variant A (candidate blocks, lambda_accept),
+//                    y = 1 variant B (current blocks, lambda_reject),
+//                    y = 2 plain sums over the candidate's items: B, g_c, sum r^2 (variant A's fields).
+// Elimination (y < 2): 16 lanes per view, 4 views per wave and trip, reading only the head of the
+// view's record. Every lane factors the view's damped 6x6 block Vh = Lc Lc^T (loaded by broadcast),
+// lane c < L forward-substitutes its row of E (z_c = Lc^-1 E_c), lane L the view gradient
+// (z_g = Lc^-1 g_v). Then sum_views E Vh^-1 [E^T | g_v] = W^T W with W = [z_0 .. z_{L-1} z_g] is one
+// more tall-skinny Gram: 6 x v_mfma_f64_16x16x4_f64 per trip, K-slot = view, no cross-lane traffic.
 constexpr int kSchurBlock = 256;
 constexpr int kSchurViewsPerBlock = kSchurBlock / 16;
 
@@ -514,60 +549,88 @@ __global__ __launch_bounds__(kSchurBlock) void schur_kernel(const double* __rest
                                                             const double* __restrict__ G1,
                                                             const LMState* __restrict__ st,
                                                             const int* __restrict__ view_item0,
-                                                            int nv, double* __restrict__ part) {
+                                                            int nv, int n_items, double* __restrict__ part) {
     constexpr int VA = variantSize(L);
-    constexpr int NACC = L + 3;                               // B column sums, g_c, nfail, sse
-    __shared__ double sacc[kSchurViewsPerBlock][16][NACC];
+    constexpr int kNfail = 2 * L * L + 2 * L, kSse = kNfail + 1;
+    __shared__ double sfail[kSchurViewsPerBlock];
     __shared__ double stile[kSchurBlock / 64][256];
     if (st->done) return;
     const int variant = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = tid & 15, grp = tid >> 4, k = lane >> 4;
-    double* out = part + ((int64_t)variant * gridDim.x + blockIdx.x) * VA;
     const bool boot = st->round == 0;
+    const int cand = st->cur ^ 1;
+
+    if (variant == 2) {
+        // thread t of each half-block owns one field of the record; a wave reads 512 contiguous bytes
+        constexpr int NF = L * L + L + 1;
+        double* out = part + (int64_t)blockIdx.x * VA;
+        const double* G = cand ? G1 : G0;
+        const int t = tid & 127, half = tid >> 7;
+        const int field = t < L * L ? kGB + t : (t < L * L + L ? kGg + (t - L * L) : kGSse);
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (t < NF) {
+            const int64_t step = (int64_t)gridDim.x * 2;
+            int64_t it = (int64_t)blockIdx.x * 2 + half;
+            const double* src = G + field;
+            for (; it + 3 * step < n_items; it += 4 * step) {
+                s0 += src[it * kGStride];
+                s1 += src[(it + step) * kGStride];
+                s2 += src[(it + 2 * step) * kGStride];
+                s3 += src[(it + 3 * step) * kGStride];
+            }
+            for (; it < n_items; it += step) s0 += src[it * kGStride];
+        }
+        double* sh = &stile[0][0];
+        sh[tid] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (tid < NF) {
+            const double tot = sh[tid] + sh[128 + tid];
+            out[tid < L * L ? tid : (tid < L * L + L ? 2 * L * L + (tid - L * L) : kSse)] = tot;
+        }
+        return;
+    }
+
+    double* out = part + ((int64_t)variant * gridDim.x + blockIdx.x) * VA;
     if (variant == 1 && boot) {       // no "current" blocks yet
         for (int i = tid; i < VA; i += kSchurBlock) out[i] = 0.0;
         return;
     }
-    const int cand = st->cur ^ 1;
     const int buf = variant == 0 ? cand : st->cur;
     const double* G = buf ? G1 : G0;
     const double lam = variant == 0 ? (boot ? st->lam : st->lam / 10) : st->lam * 10;
-    const bool sums = variant == 0;                           // variant B re-uses the state's B, g_c, err
 
     d4 acc = {0.0, 0.0, 0.0, 0.0};
-    double Bacc[L], gacc = 0.0, nfail = 0.0, eacc = 0.0;
-#pragma unroll
-    for (int i = 0; i < L; ++i) Bacc[i] = 0.0;
+    double nfail = 0.0;
     for (int v0 = blockIdx.x * kSchurViewsPerBlock; v0 < nv; v0 += gridDim.x * kSchurViewsPerBlock) {
         const int v = v0 + grp;
         double z[6];
 #pragma unroll
         for (int m = 0; m < 6; ++m) z[m] = 0.0;
         if (v < nv) {                                         // whole 16-lane group together
-            const int i0 = view_item0[v], i1 = view_item0[v + 1];
+            // view_item0 == nullptr: every view is a single item (item index == view index)
+            const int i0 = view_item0 ? view_item0[v] : v, i1 = view_item0 ? view_item0[v + 1] : v + 1;
             double V[21], b[6];
+            {
+                const double* g = G + (int64_t)i0 * kGStride;
 #pragma unroll
-            for (int i = 0; i < 21; ++i) V[i] = 0.0;
+                for (int m = 0; m < 6; ++m) {
 #pragma unroll
-            for (int m = 0; m < 6; ++m) b[m] = 0.0;
-            for (int it = i0; it < i1; ++it) {                // > 1 item only for views above kGramChunk points
+                    for (int n = 0; n <= m; ++n) V[tri(m, n)] = g[kGRows + m * 16 + L + n];
+                    // lane c < L: E[c][m] = R[m][c]; lane L: g_v[m]; lanes above: nothing
+                    const double* src = c < L ? g + kGRows + m * 16 + c : g + kGg + L + m;
+                    const double t = *src;
+                    b[m] = c <= L ? t : 0.0;
+                }
+            }
+            for (int it = i0 + 1; it < i1; ++it) {            // > 1 item only for views above kGramChunk points
                 const double* g = G + (int64_t)it * kGStride;
 #pragma unroll
                 for (int m = 0; m < 6; ++m) {
 #pragma unroll
-                    for (int n = 0; n <= m; ++n) V[tri(m, n)] += g[(L + m) * 16 + L + n];
-                    // lane c < L: E[c][m] = G[L+m][c]; lane L: g_v[m]; lanes above: nothing
-                    const double* src = c < L ? g + (L + m) * 16 + c : g + 256 + L + m;
+                    for (int n = 0; n <= m; ++n) V[tri(m, n)] += g[kGRows + m * 16 + L + n];
+                    const double* src = c < L ? g + kGRows + m * 16 + c : g + kGg + L + m;
                     const double t = *src;
                     b[m] += c <= L ? t : 0.0;
-                }
-                if (sums) {
-                    if (c < L) {
-#pragma unroll
-                        for (int rr = 0; rr < L; ++rr) Bacc[rr] += g[rr * 16 + c];
-                        gacc += g[256 + c];
-                    }
-                    if (c == 0) eacc += g[272];
                 }
             }
             // Cholesky of V + lam diag(V)  (JTJ + lam * diag(JTJ), src/calibrate.py:147,152), in place
@@ -579,7 +642,7 @@ __global__ __launch_bounds__(kSchurBlock) void schur_kernel(const double* __rest
 #pragma unroll
                 for (int q = 0; q < j; ++q) d -= V[tri(j, q)] * V[tri(j, q)];
                 if (!(d > 0.0)) fail = true;
-                const double inv = 1.0 / sqrt(d);
+                const double inv = rsqrt_nr(d);
                 invd[j] = inv;
 #pragma unroll
                 for (int i = j + 1; i < 6; ++i) {
@@ -596,7 +659,7 @@ __global__ __launch_bounds__(kSchurBlock) void schur_kernel(const double* __rest
                 for (int n = 0; n < m; ++n) t -= V[tri(m, n)] * z[n];
                 z[m] = t * invd[m];
             }
-            if (fail && c == 0) nfail += 1.0;
+            if (fail) nfail += 1.0;
         }
         // W^T W: K-slot k = this lane's view, six rows per view
 #pragma unroll
@@ -604,36 +667,28 @@ __global__ __launch_bounds__(kSchurBlock) void schur_kernel(const double* __rest
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) stile[wave][(k + 4 * reg) * 16 + c] = acc[reg];
-    if (sums) {
-#pragma unroll
-        for (int i = 0; i < L; ++i) sacc[grp][c][i] = Bacc[i];
-        sacc[grp][c][L] = gacc;
-        sacc[grp][c][L + 2] = eacc;
-    }
-    sacc[grp][c][L + 1] = nfail;
+    if (c == 0) sfail[grp] = nfail;
     __syncthreads();
-    // fixed-order sums over the block's waves / view groups
+    // fixed-order sums over the block's waves / view groups; B, g_c and sum r^2 of variant A come
+    // from the y = 2 blocks, variant B re-uses the state's copies (zeros here)
     for (int i = tid; i < L * L; i += kSchurBlock) {
         const int row = i / L, col = i - row * L;
         double t = 0.0;
         for (int w = 0; w < kSchurBlock / 64; ++w) t += stile[w][row * 16 + col];
         out[L * L + i] = t;                                   // sum E Vh^-1 E^T
-        double bsum = 0.0;
-        if (sums) for (int g = 0; g < kSchurViewsPerBlock; ++g) bsum += sacc[g][row][col];   // B[row][col] = G[col][row]
-        out[i] = bsum;
+        if (variant == 1) out[i] = 0.0;
     }
     if (tid < L) {
-        double t = 0.0, gs = 0.0;
+        double t = 0.0;
         for (int w = 0; w < kSchurBlock / 64; ++w) t += stile[w][tid * 16 + L];
-        if (sums) for (int g = 0; g < kSchurViewsPerBlock; ++g) gs += sacc[g][tid][L];
-        out[2 * L * L + tid] = gs;                            // g_c
         out[2 * L * L + L + tid] = t;                         // sum E Vh^-1 g_v
+        if (variant == 1) out[2 * L * L + tid] = 0.0;
     }
     if (tid == 0) {
-        double nf = 0.0, e = 0.0;
-        for (int g = 0; g < kSchurViewsPerBlock; ++g) { nf += sacc[g][0][L + 1]; if (sums) e += sacc[g][0][L + 2]; }
-        out[2 * L * L + 2 * L] = nf;
-        out[2 * L * L + 2 * L + 1] = e;
+        double nf = 0.0;
+        for (int g = 0; g < kSchurViewsPerBlock; ++g) nf += sfail[g];
+        out[kNfail] = nf;
+        if (variant == 1) out[kSse] = 0.0;
     }
 }
 
@@ -865,11 +920,11 @@ __global__ __launch_bounds__(kSchurThreads) void update_backsub_kernel(
     double* Pn = cur ? P0 : P1;
     // grid-stride over views: the decision / solve above is paid once per workgroup, not per view
     for (int v = blockIdx.x * (kSchurThreads / 16) + (tid >> 4); v < nv; v += gridDim.x * (kSchurThreads / 16)) {
-    double col[16], gc, sse;
-    const int i0 = view_item0[v];
-    load_view_col(G, i0, view_item0[v + 1] - i0, c, col, gc, sse);
+    double b[6], gc;
+    const int i0 = view_item0 ? view_item0[v] : v;
+    load_view_rows(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, b, gc);
     Elim<L> e;
-    eliminate<L>(col, gc, lam, e);
+    eliminate<L>(b, gc, lam, e);
     double dcc = 0.0;
 #pragma unroll
     for (int j = 0; j < L; ++j) if (j == c) dcc = dc[j];
