@@ -479,32 +479,34 @@ struct Elim {
     bool fail;
 };
 
-// this lane's column of the view rows R (b[m] = R[m][c]) and of g, summed over the view's items
-__device__ __forceinline__ void load_view_rows(const double* __restrict__ G, int item0, int nitems,
-                                               int c, double (&b)[6], double& gc) {
+// the head of a view's record(s) as the elimination wants it: V (lower triangle, the same for all
+// 16 lanes: broadcast loads), this lane's column of the view rows (b[m] = R[m][c]), g_view
+template <int L>
+__device__ __forceinline__ void load_view_head(const double* __restrict__ G, int item0, int nitems, int c,
+                                               double (&V)[21], double (&b)[6], double (&gv)[6]) {
     const double* g = G + (int64_t)item0 * kGStride;
 #pragma unroll
-    for (int m = 0; m < 6; ++m) b[m] = g[kGRows + m * 16 + c];
-    gc = g[kGg + c];
+    for (int m = 0; m < 6; ++m) {
+#pragma unroll
+        for (int n = 0; n <= m; ++n) V[tri(m, n)] = g[kGRows + m * 16 + L + n];
+        b[m] = g[kGRows + m * 16 + c];
+        gv[m] = g[kGg + L + m];
+    }
     for (int it = 1; it < nitems; ++it) {                     // > 1 item only for views above kGramChunk points
         g += kGStride;
 #pragma unroll
-        for (int m = 0; m < 6; ++m) b[m] += g[kGRows + m * 16 + c];
-        gc += g[kGg + c];
+        for (int m = 0; m < 6; ++m) {
+#pragma unroll
+            for (int n = 0; n <= m; ++n) V[tri(m, n)] += g[kGRows + m * 16 + L + n];
+            b[m] += g[kGRows + m * 16 + c];
+            gv[m] += g[kGg + L + m];
+        }
     }
 }
 
 template <int L>
-__device__ __forceinline__ void eliminate(const double (&b)[6], double gc, double lam,
-                                          Elim<L>& e) {
-    double V[21];
-#pragma unroll
-    for (int m = 0; m < 6; ++m)
-#pragma unroll
-        for (int n = 0; n <= m; ++n) V[tri(m, n)] = __shfl(b[m], L + n, 16);
-    double gv[6];
-#pragma unroll
-    for (int m = 0; m < 6; ++m) gv[m] = __shfl(gc, L + m, 16);
+__device__ __forceinline__ void eliminate(const double (&V)[21], const double (&b)[6], const double (&gv)[6],
+                                          double lam, Elim<L>& e) {
     e.fail = false;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -725,20 +727,50 @@ __global__ __launch_bounds__(256) void sse_reduce_kernel(const double* __restric
     if (tid == 0) out[0] = ssum[0];
 }
 
+// Cross-lane traffic inside a 16-lane view group rides on DPP (a 16-lane group is exactly one DPP
+// row): VALU latency, no trip through the LDS crossbar as with ds_bpermute. The four exchange
+// patterns below (lane ^ 1, lane ^ 2, mirror inside each half row, mirror of the row) pair every lane
+// with the same partner sets as an xor butterfly, so sums come out bit-identical on all 16 lanes.
+constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;  // row_half_mirror: lane i <- lane 7 - i of its half row
+constexpr int kDppMirror = 0x140;      // row_mirror: lane i <- lane 15 - i of its row
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    return __hiloint2double(dpp_i<CTRL>(__double2hiint(v)), dpp_i<CTRL>(__double2loint(v)));
+}
+// lane a (0..3) of every quad to the four lanes of that quad
+template <int A>
+__device__ __forceinline__ double quad_bcast(double v) { return dpp_d<A * 0x55>(v); }
+
 // sum over the 16 lanes of a view group
 __device__ __forceinline__ double group_sum16(double v) {
-    v += __shfl_xor(v, 1, 16);
-    v += __shfl_xor(v, 2, 16);
-    v += __shfl_xor(v, 4, 16);
-    v += __shfl_xor(v, 8, 16);
+    v += dpp_d<kDppXor1>(v);
+    v += dpp_d<kDppXor2>(v);
+    v += dpp_d<kDppHalfMirror>(v);
+    v += dpp_d<kDppMirror>(v);
     return v;
+}
+
+// a / b with a v_rcp_f64 seed, two Newton steps and one residual correction of the quotient
+__device__ __forceinline__ double div_nr(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
 }
 
 // ---------------------------------------------------------------- N x N solve on 16 lanes
 // Gauss-Jordan with partial pivoting; lane i < N owns row i of [S | s] (row[N] = rhs), lanes >= N
 // hold zero rows. On return the lane that served as pivot row for column myCol holds x[myCol] in d
 // (myCol = -1 on the other lanes). Returns true when a pivot is exactly zero / not finite.
-template <int N>
+// WAVE0: the caller runs in lanes 0..15 of its wave only (the other lanes inactive), so the pivot
+// row is a wave-uniform lane and its broadcast a v_readlane; otherwise one ds_bpermute per dword.
+template <int N, bool WAVE0 = false>
 __device__ __forceinline__ bool gauss_jordan16(double (&row)[N + 1], int i, int& myCol, double& d) {
     bool used = false, singular = false;
     myCol = -1;
@@ -746,21 +778,30 @@ __device__ __forceinline__ bool gauss_jordan16(double (&row)[N + 1], int i, int&
     for (int col = 0; col < N; ++col) {
         double best = (!used && i < N) ? fabs(row[col]) : -1.0;
         int bi = i;
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {
-            const double ob = __shfl_xor(best, off, 16);
-            const int oi = __shfl_xor(bi, off, 16);
+        auto take = [&](double ob, int oi) {
             if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-        }
+        };
+        take(dpp_d<kDppXor1>(best), dpp_i<kDppXor1>(bi));
+        take(dpp_d<kDppXor2>(best), dpp_i<kDppXor2>(bi));
+        take(dpp_d<kDppHalfMirror>(best), dpp_i<kDppHalfMirror>(bi));
+        take(dpp_d<kDppMirror>(best), dpp_i<kDppMirror>(bi));
         if (!(best > 0.0)) singular = true;
         double prow[N + 1];
+        if (WAVE0) {
+            const int sb = __builtin_amdgcn_readfirstlane(bi);
 #pragma unroll
-        for (int j = col; j <= N; ++j) prow[j] = __shfl(row[j], bi, 16);
+            for (int j = col; j <= N; ++j)
+                prow[j] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(row[j]), sb),
+                                           __builtin_amdgcn_readlane(__double2loint(row[j]), sb));
+        } else {
+#pragma unroll
+            for (int j = col; j <= N; ++j) prow[j] = __shfl(row[j], bi, 16);
+        }
         if (i == bi) {
             used = true;
             myCol = col;
         } else {
-            const double f = row[col] / prow[col];
+            const double f = div_nr(row[col], prow[col]);
 #pragma unroll
             for (int j = col + 1; j <= N; ++j) row[j] -= f * prow[j];
             row[col] = 0.0;
@@ -851,7 +892,7 @@ __device__ __forceinline__ bool lm_update_step(const LMState* __restrict__ in, L
     }
     int myCol = -1;
     double d = 0.0;
-    if (!done && gauss_jordan16<L>(row, i, myCol, d)) { error = -3; done = true; }
+    if (!done && gauss_jordan16<L, true>(row, i, myCol, d)) { error = -3; done = true; }
 #pragma unroll
     for (int c = 0; c < L; ++c) dc[c] = group_sum16(myCol == c ? d : 0.0);
 
@@ -920,11 +961,11 @@ __global__ __launch_bounds__(kSchurThreads) void update_backsub_kernel(
     double* Pn = cur ? P0 : P1;
     // grid-stride over views: the decision / solve above is paid once per workgroup, not per view
     for (int v = blockIdx.x * (kSchurThreads / 16) + (tid >> 4); v < nv; v += gridDim.x * (kSchurThreads / 16)) {
-    double b[6], gc;
+    double V[21], b[6], gv[6];
     const int i0 = view_item0 ? view_item0[v] : v;
-    load_view_rows(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, b, gc);
+    load_view_head<L>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b, gv);
     Elim<L> e;
-    eliminate<L>(b, gc, lam, e);
+    eliminate<L>(V, b, gv, lam, e);
     double dcc = 0.0;
 #pragma unroll
     for (int j = 0; j < L; ++j) if (j == c) dcc = dc[j];
@@ -952,16 +993,17 @@ __global__ __launch_bounds__(kSchurThreads) void update_backsub_kernel(
     }
     // view constants of the candidate (layout of view_setup_kernel)
     const double deg = 0.017453292519943295;
-    // one sincos per wave instruction stream: lane a (< 3) of the group takes angle a, the results
-    // are handed round by shuffles
+    // one sincos per wave instruction stream: lane a (< 3) of each quad takes angle a, the results
+    // are handed round inside the quad (DPP quad_perm)
     double sn[3], cs[3];
     {
-        const double th = (c == 1 ? en[1] : (c == 2 ? en[2] : en[0])) * deg;
+        const int a = c & 3;                             // every quad evaluates the three angles itself
+        const double th = (a == 1 ? en[1] : (a == 2 ? en[2] : en[0])) * deg;
         double s1, c1;
         sincos(th, &s1, &c1);
         if (fabs(th) <= 1e-8) { s1 = 0.0; c1 = 1.0; }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { sn[a] = __shfl(s1, a, 16); cs[a] = __shfl(c1, a, 16); }
+        sn[0] = quad_bcast<0>(s1); sn[1] = quad_bcast<1>(s1); sn[2] = quad_bcast<2>(s1);
+        cs[0] = quad_bcast<0>(c1); cs[1] = quad_bcast<1>(c1); cs[2] = quad_bcast<2>(c1);
     }
     const double sx = sn[0], cx = cs[0], sy = sn[1], cy = cs[1], sz = sn[2], cz = cs[2];
     const double o18[18] = {cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx,
