@@ -470,27 +470,20 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
     return r;
 }
 
-template <int L>
-struct Elim {
-    double Lc[21];    // Cholesky factor of V + lam diag(V) (strictly lower part; diagonal slots unused)
-    double invd[6];   // 1 / diagonal of the factor
-    double z[6];      // Lc^-1 (this lane's column restricted to the view rows)
-    double zg[6];     // Lc^-1 g_view
-    bool fail;
-};
-
-// the head of a view's record(s) as the elimination wants it: V (lower triangle, the same for all
-// 16 lanes: broadcast loads), this lane's column of the view rows (b[m] = R[m][c]), g_view
+// The head of a view's record(s) as the elimination wants it: V (lower triangle of the 6x6 view block,
+// the same for all 16 lanes: broadcast loads) and this lane's right-hand side b -- lane c < L: row c
+// of E (E[c][m] = R[m][c]); lanes >= L: the view gradient g_v.
 template <int L>
 __device__ __forceinline__ void load_view_head(const double* __restrict__ G, int item0, int nitems, int c,
-                                               double (&V)[21], double (&b)[6], double (&gv)[6]) {
+                                               double (&V)[21], double (&b)[6]) {
     const double* g = G + (int64_t)item0 * kGStride;
+    const int boff = c < L ? kGRows + c : kGg + L;            // + m * 16 (view rows) resp. + m (gradient)
+    const int bstep = c < L ? 16 : 1;
 #pragma unroll
     for (int m = 0; m < 6; ++m) {
 #pragma unroll
         for (int n = 0; n <= m; ++n) V[tri(m, n)] = g[kGRows + m * 16 + L + n];
-        b[m] = g[kGRows + m * 16 + c];
-        gv[m] = g[kGg + L + m];
+        b[m] = g[boff + m * bstep];
     }
     for (int it = 1; it < nitems; ++it) {                     // > 1 item only for views above kGramChunk points
         g += kGStride;
@@ -498,40 +491,42 @@ __device__ __forceinline__ void load_view_head(const double* __restrict__ G, int
         for (int m = 0; m < 6; ++m) {
 #pragma unroll
             for (int n = 0; n <= m; ++n) V[tri(m, n)] += g[kGRows + m * 16 + L + n];
-            b[m] += g[kGRows + m * 16 + c];
-            gv[m] += g[kGg + L + m];
+            b[m] += g[boff + m * bstep];
         }
     }
 }
 
-template <int L>
-__device__ __forceinline__ void eliminate(const double (&V)[21], const double (&b)[6], const double (&gv)[6],
-                                          double lam, Elim<L>& e) {
-    e.fail = false;
+// Cholesky of V + lam diag(V) (JTJ + lam * diag(JTJ), src/calibrate.py:147,152) in place -- on return
+// the strictly lower part of V is the factor Lc, invd the reciprocal of its diagonal -- and the
+// forward substitution z = Lc^-1 b of this lane's right-hand side. Returns false when a pivot is
+// not positive.
+__device__ __forceinline__ bool eliminate(double (&V)[21], const double (&b)[6], double lam,
+                                          double (&invd)[6], double (&z)[6]) {
+    bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        double d = V[tri(j, j)] + lam * V[tri(j, j)];     // JTJ + lam * diag(JTJ), src/calibrate.py:147,152
+        double d = V[tri(j, j)] + lam * V[tri(j, j)];
 #pragma unroll
-        for (int q = 0; q < j; ++q) d -= e.Lc[tri(j, q)] * e.Lc[tri(j, q)];
-        if (!(d > 0.0)) e.fail = true;
+        for (int q = 0; q < j; ++q) d -= V[tri(j, q)] * V[tri(j, q)];
+        if (!(d > 0.0)) ok = false;
         const double inv = rsqrt_nr(d);
-        e.invd[j] = inv;
+        invd[j] = inv;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             double t = V[tri(i, j)];
 #pragma unroll
-            for (int q = 0; q < j; ++q) t -= e.Lc[tri(i, q)] * e.Lc[tri(j, q)];
-            e.Lc[tri(i, j)] = t * inv;
+            for (int q = 0; q < j; ++q) t -= V[tri(i, q)] * V[tri(j, q)];
+            V[tri(i, j)] = t * inv;
         }
     }
 #pragma unroll
     for (int m = 0; m < 6; ++m) {
-        double t = b[m], tg = gv[m];
+        double t = b[m];
 #pragma unroll
-        for (int n = 0; n < m; ++n) { t -= e.Lc[tri(m, n)] * e.z[n]; tg -= e.Lc[tri(m, n)] * e.zg[n]; }
-        e.z[m] = t * e.invd[m];
-        e.zg[m] = tg * e.invd[m];
+        for (int n = 0; n < m; ++n) t -= V[tri(m, n)] * z[n];
+        z[m] = t * invd[m];
     }
+    return ok;
 }
 
 // ---------------------------------------------------------------- schur partials
@@ -610,57 +605,15 @@ __global__ __launch_bounds__(kSchurBlock) void schur_kernel(const double* __rest
         for (int m = 0; m < 6; ++m) z[m] = 0.0;
         if (v < nv) {                                         // whole 16-lane group together
             // view_item0 == nullptr: every view is a single item (item index == view index)
-            const int i0 = view_item0 ? view_item0[v] : v, i1 = view_item0 ? view_item0[v + 1] : v + 1;
-            double V[21], b[6];
-            {
-                const double* g = G + (int64_t)i0 * kGStride;
+            const int i0 = view_item0 ? view_item0[v] : v;
+            double V[21], b[6], invd[6];
+            load_view_head<L>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
+            const bool ok = eliminate(V, b, lam, invd, z);
+            if (c > L) {                                      // lanes above the gradient column contribute nothing
 #pragma unroll
-                for (int m = 0; m < 6; ++m) {
-#pragma unroll
-                    for (int n = 0; n <= m; ++n) V[tri(m, n)] = g[kGRows + m * 16 + L + n];
-                    // lane c < L: E[c][m] = R[m][c]; lane L: g_v[m]; lanes above: nothing
-                    const double* src = c < L ? g + kGRows + m * 16 + c : g + kGg + L + m;
-                    const double t = *src;
-                    b[m] = c <= L ? t : 0.0;
-                }
+                for (int m = 0; m < 6; ++m) z[m] = 0.0;
             }
-            for (int it = i0 + 1; it < i1; ++it) {            // > 1 item only for views above kGramChunk points
-                const double* g = G + (int64_t)it * kGStride;
-#pragma unroll
-                for (int m = 0; m < 6; ++m) {
-#pragma unroll
-                    for (int n = 0; n <= m; ++n) V[tri(m, n)] += g[kGRows + m * 16 + L + n];
-                    const double* src = c < L ? g + kGRows + m * 16 + c : g + kGg + L + m;
-                    const double t = *src;
-                    b[m] += c <= L ? t : 0.0;
-                }
-            }
-            // Cholesky of V + lam diag(V)  (JTJ + lam * diag(JTJ), src/calibrate.py:147,152), in place
-            double invd[6];
-            bool fail = false;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                double d = V[tri(j, j)] + lam * V[tri(j, j)];
-#pragma unroll
-                for (int q = 0; q < j; ++q) d -= V[tri(j, q)] * V[tri(j, q)];
-                if (!(d > 0.0)) fail = true;
-                const double inv = rsqrt_nr(d);
-                invd[j] = inv;
-#pragma unroll
-                for (int i = j + 1; i < 6; ++i) {
-                    double t = V[tri(i, j)];
-#pragma unroll
-                    for (int q = 0; q < j; ++q) t -= V[tri(i, q)] * V[tri(j, q)];
-                    V[tri(i, j)] = t * inv;
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < 6; ++m) {
-                double t = b[m];
-#pragma unroll
-                for (int n = 0; n < m; ++n) t -= V[tri(m, n)] * z[n];
-                z[m] = t * invd[m];
-            }
+            const bool fail = !ok;
             if (fail) nfail += 1.0;
         }
         // W^T W: K-slot k = this lane's view, six rows per view
@@ -928,7 +881,7 @@ __device__ __forceinline__ bool lm_update_step(const LMState* __restrict__ in, L
 // into the rotation / derivative-axis constants the next round's point kernels read (what
 // view_setup_kernel does for round 0).
 template <int L, typename T>
-__global__ __launch_bounds__(kSchurThreads) void update_backsub_kernel(
+__global__ __launch_bounds__(kSchurThreads, 4) void update_backsub_kernel(
         const double* __restrict__ G0, const double* __restrict__ G1, const LMState* __restrict__ st_in,
         LMState* __restrict__ st_out, const double* __restrict__ red, const int* __restrict__ view_item0,
         const int* __restrict__ view_ext, int nv, double* __restrict__ P0, double* __restrict__ P1,
@@ -954,32 +907,28 @@ __global__ __launch_bounds__(kSchurThreads) void update_backsub_kernel(
     if (sdec[0] == 0.0) return;
     cur = (int)sdec[1];
     lam = sdec[2];
-#pragma unroll
-    for (int j = 0; j < L; ++j) dc[j] = sdec[3 + j];
+    const double coef = c < L ? -sdec[3 + c] : (c == L ? 1.0 : 0.0);
     const double* G = cur ? G1 : G0;
     const double* Pc = cur ? P1 : P0;
     double* Pn = cur ? P0 : P1;
     // grid-stride over views: the decision / solve above is paid once per workgroup, not per view
     for (int v = blockIdx.x * (kSchurThreads / 16) + (tid >> 4); v < nv; v += gridDim.x * (kSchurThreads / 16)) {
-    double V[21], b[6], gv[6];
+    double V[21], b[6], invd[6], z[6];
     const int i0 = view_item0 ? view_item0[v] : v;
-    load_view_head<L>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b, gv);
-    Elim<L> e;
-    eliminate<L>(V, b, gv, lam, e);
-    double dcc = 0.0;
-#pragma unroll
-    for (int j = 0; j < L; ++j) if (j == c) dcc = dc[j];
+    load_view_head<L>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
+    eliminate(V, b, lam, invd, z);
+    // w = Lc^-1 (g_v - E^T dc): lane c < L carries -dc[c] z_c, lane L the gradient's z_g
     double w[6];
 #pragma unroll
-    for (int m = 0; m < 6; ++m) w[m] = e.zg[m] - group_sum16(dcc * e.z[m]);
+    for (int m = 0; m < 6; ++m) w[m] = group_sum16(coef * z[m]);
     // Lc^T d = w
     double d[6];
 #pragma unroll
     for (int m = 5; m >= 0; --m) {
         double t = w[m];
 #pragma unroll
-        for (int n = m + 1; n < 6; ++n) t -= e.Lc[tri(n, m)] * d[n];
-        d[m] = t * e.invd[m];
+        for (int n = m + 1; n < 6; ++n) t -= V[tri(n, m)] * d[n];
+        d[m] = t * invd[m];
     }
     const int64_t o = L + 6 * (int64_t)view_ext[v];
     double en[6];
