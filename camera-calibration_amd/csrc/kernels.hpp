@@ -308,7 +308,7 @@ constexpr int kFusedRowChunks = 17;                       // 16 columns + 1 pad 
 // ROWS = points transposed per LDS pass (32: two passes per 64-point batch, half the lanes
 // writing each time; 64: one pass, twice the LDS). WAVES = waves per workgroup.
 template <int MODEL, typename T, int ROWS, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restrict__ P0, const double* __restrict__ P1,
+__global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) void fused_kernel(const double* __restrict__ P0, const double* __restrict__ P1,
                                                     const typename Pair<T>::type* __restrict__ uv,
                                                     const typename Pair<T>::type* __restrict__ XY,
                                                     const T* __restrict__ Z, const T* __restrict__ VC,
@@ -393,16 +393,34 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
                 }
                 __builtin_amdgcn_wave_barrier();
                 const int rows = qend - (q0 + ROWS * half);     // valid points in this pass (may exceed ROWS)
+                if (rows >= ROWS) {
+                    // full pass: no tests between the LDS reads and the MFMAs, so the operand reads go
+                    // out together and the two accumulators (u rows, v rows) are fed back to back
+                    T2 jv[ROWS / 4];
 #pragma unroll
-                for (int s = 0; s < ROWS / 4; ++s) {
-                    if (4 * s >= rows) break;                   // wave-uniform
-                    const T2 jv = slab[(4 * s + k) * RS + c];
-                    double jx = (double)jv.x, jy = (double)jv.y;
-                    const bool dead = 4 * s + 4 > rows && 4 * s + k >= rows;   // partial last group (outer test wave-uniform)
-                    if (dead) { jx = 0.0; jy = 0.0; }
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jx, jx, acc, 0, 0, 0);
-                    if (ONES) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc2, 0, 0, 0);
-                    else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc, 0, 0, 0);
+                    for (int s = 0; s < ROWS / 4; ++s) jv[s] = slab[(4 * s + k) * RS + c];
+#pragma unroll
+                    for (int s = 0; s < ROWS / 4; ++s) {
+                        const double jx = (double)jv[s].x, jy = (double)jv[s].y;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jx, jx, acc, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc2, 0, 0, 0);
+                    }
+                } else {
+                    // partial pass: two groups per trip (the second may lie past the end: stale rows, skipped)
+#pragma unroll
+                    for (int s = 0; s < ROWS / 4; s += 2) {
+                        if (4 * s >= rows) break;                   // wave-uniform
+                        const T2 ja = slab[(4 * s + k) * RS + c], jb = slab[(4 * s + 4 + k) * RS + c];
+                        double jx = (double)ja.x, jy = (double)ja.y;
+                        if (4 * s + k >= rows) { jx = 0.0; jy = 0.0; }          // points past the end of the last group
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jx, jx, acc, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc2, 0, 0, 0);
+                        if (4 * s + 4 >= rows) break;               // wave-uniform
+                        jx = (double)jb.x; jy = (double)jb.y;
+                        if (4 * s + 4 + k >= rows) { jx = 0.0; jy = 0.0; }
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jx, jx, acc, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc2, 0, 0, 0);
+                    }
                 }
             }
         }
@@ -416,9 +434,9 @@ __global__ __launch_bounds__(64 * WAVES) void fused_kernel(const double* __restr
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int row = k + 4 * reg;
-                gPut<L>(dst, row, c, (c == 15 || row == 15) ? 0.0 : acc[reg]);
+                gPut<L>(dst, row, c, (c == 15 || row == 15) ? 0.0 : acc[reg] + acc2[reg]);
             }
-            if (k == 3) dst[c == 15 ? kGSse : kGg + c] = acc[3];  // lanes of row 15: J^T r (c < 15), sum r^2 (c = 15)
+            if (k == 3) dst[c == 15 ? kGSse : kGg + c] = acc[3] + acc2[3];  // lanes of row 15: J^T r (c < 15), sum r^2 (c = 15)
             if (k == 0 && c == 15) dst[kGg + 15] = 0.0;
         } else {
 #pragma unroll
