@@ -81,6 +81,7 @@ struct calib_handle_s {
     int64_t max_chunk_points = 0;
     DevBuf<unsigned char> uv, XY, Z, VC, J, r, y;   // typed by dtype
     DevBuf<int> pt_view, view_ext, item_n, view_item0, item_view;
+    DevBuf<uint32_t> emit_tab;    // fused kernel's record assembly table (buildEmitTable)
     int lm_mode = CALIB_LM_FUSED;
     DevBuf<int64_t> item_pt0;
     DevBuf<double> sse_part, G[2], part, red_own, P[2], Peval, trace;
@@ -205,7 +206,7 @@ int launch_fused_t(calib_handle_s* h, const LMState* st, int sel) {
     hipLaunchKernelGGL((fused_kernel<MODEL, T, 32, 4>), dim3(blocks), dim3(256), 0, h->stream, h->P[0].p,
                        h->P[1].p, reinterpret_cast<const T2*>(h->uv.p), reinterpret_cast<const T2*>(h->XY.p),
                        reinterpret_cast<const T*>(h->Z.p), reinterpret_cast<const T*>(h->VC.p), h->item_pt0.p,
-                       h->item_n.p, h->item_view.p, h->n_items, wpi, st, sel, h->G[0].p, h->G[1].p);
+                       h->item_n.p, h->item_view.p, h->n_items, wpi, h->emit_tab.p, st, sel, h->G[0].p, h->G[1].p);
     prof_end(h, pi);
     HIP_TRY(hipGetLastError());
     return CALIB_OK;
@@ -315,6 +316,18 @@ int calib_create(int model, int dtype, int device_id, calib_handle_t* out_handle
         return fail(CALIB_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
     h->stream = h->own_stream;
+    {
+        uint32_t tab[kGStride];
+        buildEmitTable(h->C, tab);
+        e = h->emit_tab.alloc(kGStride);
+        if (e == hipSuccess) e = hipMemcpy(h->emit_tab.p, tab, sizeof(tab), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            h->emit_tab.release();
+            (void)hipStreamDestroy(h->own_stream);
+            delete h;
+            return fail(CALIB_E_HIP, std::string("emit table: ") + hipGetErrorString(e));
+        }
+    }
     if (const char* e = std::getenv("CALIB_LM_MODE")) h->lm_mode = std::atoi(e) ? CALIB_LM_TWO_KERNEL : CALIB_LM_FUSED;
     *out_handle = h;
     return CALIB_OK;
@@ -328,6 +341,7 @@ int calib_destroy(calib_handle_t h) {
     h->uv.release(); h->XY.release(); h->Z.release(); h->VC.release(); h->J.release();
     h->r.release(); h->y.release(); h->pt_view.release(); h->view_ext.release();
     h->item_n.release(); h->view_item0.release(); h->item_view.release(); h->item_pt0.release(); h->sse_part.release();
+    h->emit_tab.release();
     h->G[0].release(); h->G[1].release(); h->part.release(); h->red_own.release();
     h->P[0].release(); h->P[1].release(); h->Peval.release(); h->trace.release();
     h->st.release(); h->st_eval.release();

@@ -45,6 +45,41 @@ __device__ __forceinline__ void gPut(double* dst, int row, int col, double val) 
 }
 __device__ __forceinline__ bool gLive(int i, int L) { return i < kGHead || (i >= kGB && i < kGB + L * L); }
 
+// Fused kernel: how record slot i is assembled from the two accumulator tiles of a wave (TU: the u
+// rows of J, TV: the v rows): slot i = TU[tab[i] & 0xffff] + TV[tab[i] >> 16], tile index row * 16 +
+// col, kEmitZero = "nothing". Fisheye (C = 15): the residual rides in MFMA column 15, so both tiles
+// are plain J^T J with J^T r in row 15 and sum r^2 in the corner. Radial-tangential (C = 16):
+// J's constant columns 3 and 4, (1,0) and (0,1), are replaced by one column of (1,1) -- TU[.][3] =
+// sum Ju, TV[.][3] = sum Jv -- and column 4 carries the residual (see fused_kernel).
+constexpr int kEmitZero = 256;
+constexpr int kEmitTile = 264;        // doubles per tile in LDS: 256 + the zero slot, padded
+inline void buildEmitTable(int C, uint32_t* tab /* kGStride */) {
+    const int L = C - 6;
+    const auto both = [](int idx) { return (uint32_t)idx | ((uint32_t)idx << 16); };
+    const auto pick = [](int iu, int iv) { return (uint32_t)iu | ((uint32_t)iv << 16); };
+    const int Z = kEmitZero;
+    // entry (row, col) of the true J^T J
+    const auto entry = [&](int row, int col) -> uint32_t {
+        if (C == 15) return col == 15 ? both(Z) : both(row * 16 + col);
+        const bool rs = row == 3 || row == 4, cs = col == 3 || col == 4;
+        if (!rs && !cs) return both(row * 16 + col);
+        if (!rs) return col == 3 ? pick(row * 16 + 3, Z) : pick(Z, row * 16 + 3);      // sum Ju[row] / sum Jv[row]
+        if (!cs) return row == 3 ? pick(3 * 16 + col, Z) : pick(Z, 3 * 16 + col);
+        if (row != col) return both(Z);                                                  // (1,0).(0,1) = 0
+        return row == 3 ? pick(3 * 16 + 3, Z) : pick(Z, 3 * 16 + 3);                     // point count
+    };
+    for (int i = 0; i < kGStride; ++i) tab[i] = both(Z);
+    for (int m = 0; m < 6; ++m)
+        for (int c = 0; c < 16; ++c) tab[kGRows + m * 16 + c] = entry(L + m, c);
+    for (int r = 0; r < L; ++r)
+        for (int c = 0; c < L; ++c) tab[kGB + r * L + c] = entry(r, c);
+    for (int c = 0; c < C; ++c) {
+        if (C == 15) tab[kGg + c] = both(15 * 16 + c);
+        else tab[kGg + c] = c == 3 ? pick(3 * 16 + 4, Z) : (c == 4 ? pick(Z, 3 * 16 + 4) : both(c * 16 + 4));
+    }
+    tab[kGSse] = C == 15 ? both(15 * 16 + 15) : both(4 * 16 + 4);
+}
+
 // Compact Jacobian in HBM: groups of 4 points, [group][column][point-in-group] of (du, dv) pairs.
 // The jacobian kernel's store of one column then writes 64 B per 4 lanes (instead of 16 B per
 // lane at a C*16 B stride), and the 4 points x 16 columns a gram wave-load needs are still one
@@ -315,6 +350,7 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
                                                     const int64_t* __restrict__ item_pt0,
                                                     const int* __restrict__ item_n,
                                                     const int* __restrict__ item_view, int n_items, int wpi,
+                                                    const uint32_t* __restrict__ emit_tab,
                                                     const LMState* __restrict__ st, int sel,
                                                     double* __restrict__ G0, double* __restrict__ G1) {
     using T2 = typename Pair<T>::type;
@@ -328,9 +364,8 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
     // tile_v[.][3] = sum Jv, i.e. what columns 3 and 4 used to give -- and column 4 the residual
     // (ru, rv): (tile_u + tile_v)[.][4] = J^T r, [4][4] = sum r^2, tile_u[3][4] = sum ru, tile_v[3][4] = sum rv.
     constexpr bool ONES = !RCOL;
-    // one slab per wave; after the main loop the same memory holds the wave partial tiles
-    __shared__ __attribute__((aligned(16))) unsigned char smem[WAVES * SLAB * sizeof(T2) > WAVES * kGStride * 8
-                                                                     ? WAVES * SLAB * sizeof(T2) : WAVES * kGStride * 8];
+    // one slab per wave; after the main loop the same memory holds the wave's two accumulator tiles
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WAVES * SLAB * sizeof(T2)];
     if (sel && st->done) return;
     const double* P = selectP(P0, P1, st, sel);
     const int lane = threadIdx.x & 63;
@@ -425,52 +460,40 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
             }
         }
     }
-    // tile (f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg), J^T r, sum r^2 -> record at dst.
-    // With the residual in column 15 the tile's last row is J^T r and its corner sum r^2; column 15 of
-    // the stored view rows is zero either way (what the elimination kernels expect).
-    constexpr int L = C - 6;
-    auto emit = [&](double* dst) {
-        if (RCOL) {
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int row = k + 4 * reg;
-                gPut<L>(dst, row, c, (c == 15 || row == 15) ? 0.0 : acc[reg] + acc2[reg]);
-            }
-            if (k == 3) dst[c == 15 ? kGSse : kGg + c] = acc[3] + acc2[3];  // lanes of row 15: J^T r (c < 15), sum r^2 (c = 15)
-            if (k == 0 && c == 15) dst[kGg + 15] = 0.0;
-        } else {
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int row = k + 4 * reg;
-                const double U = acc[reg], V = acc2[reg];
-                const bool rs = row == 3 || row == 4, cs = c == 3 || c == 4;
-                if (!rs && !cs) gPut<L>(dst, row, c, U + V);
-                else if (!rs && c == 3) { gPut<L>(dst, row, 3, U); gPut<L>(dst, row, 4, V); }     // sum Ju[row], sum Jv[row]
-                else if (!rs && c == 4) dst[kGg + row] = U + V;                                    // J^T r
-                else if (row == 3 && !cs) { gPut<L>(dst, 3, c, U); gPut<L>(dst, 4, c, V); }
-                else if (row == 3 && c == 3) { gPut<L>(dst, 3, 3, U); gPut<L>(dst, 4, 4, V); gPut<L>(dst, 3, 4, 0.0); gPut<L>(dst, 4, 3, 0.0); }
-                else if (row == 3 && c == 4) { dst[kGg + 3] = U; dst[kGg + 4] = V; }               // sum ru, sum rv
-                else if (row == 4 && c == 4) dst[kGSse] = U + V;                                   // sum r^2
-            }
-        }
-    };
+    // Record assembly: the wave parks its two accumulator tiles (f64 MFMA C/D layout: col = lane & 15,
+    // row = (lane >> 4) + 4 * reg) in its dead slab, then every lane builds two adjacent record slots
+    // per pass from the table -- no case analysis, two 1 KiB-coalesced stores per item.
+    static_assert(SLAB * sizeof(T2) >= 2 * kEmitTile * 8, "tiles must fit the wave's slab");
+    double* TU = reinterpret_cast<double*>(slab);
+    double* TV = TU + kEmitTile;
     double* Gbase = sel ? ((st->cur ^ 1) ? G1 : G0) : G0;
-    if (wpi == 1) {
-        if (!valid) return;
-        emit(Gbase + (int64_t)item * kGStride);
-        return;
+    if (wpi > 1) __syncthreads();                               // partner waves may still read their slabs
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        TU[(k + 4 * reg) * 16 + c] = acc[reg];
+        TV[(k + 4 * reg) * 16 + c] = acc2[reg];
     }
-    __syncthreads();                                            // slabs are dead, reuse as partial tiles
-    double* sred = reinterpret_cast<double*>(smem);
-    emit(sred + wave * kGStride);
-    __syncthreads();
-    if (sub == 0 && valid) {
-        double* G = Gbase + (int64_t)item * kGStride;
-        for (int i = lane; i < kGStride; i += 64) {
-            if (!gLive(i, L)) continue;
-            double t = sred[wave * kGStride + i];
-            for (int w = 1; w < wpi; ++w) t += sred[(wave + w) * kGStride + i];
-            G[i] = t;
+    if (lane == 0) { TU[kEmitZero] = 0.0; TV[kEmitZero] = 0.0; }
+    if (wpi > 1) __syncthreads();
+    __builtin_amdgcn_wave_barrier();
+    if (sub != 0 || !valid) return;                             // the item's first wave assembles the record
+    double* G = Gbase + (int64_t)item * kGStride;
+#pragma unroll
+    for (int pass = 0; pass < (kGStride + 127) / 128; ++pass) {
+        const int i0 = 128 * pass + 2 * lane;
+        if (i0 < kGStride) {
+            const uint2 t = *reinterpret_cast<const uint2*>(emit_tab + i0);
+            double2 o;
+            o.x = TU[t.x & 0xffff] + TV[t.x >> 16];
+            o.y = TU[t.y & 0xffff] + TV[t.y >> 16];
+            for (int w = 1; w < wpi; ++w) {                     // partial tiles of the item's other waves, in wave order
+                const double* TUw = reinterpret_cast<const double*>(slab + w * SLAB);
+                const double* TVw = TUw + kEmitTile;
+                o.x += TUw[t.x & 0xffff] + TVw[t.x >> 16];
+                o.y += TUw[t.y & 0xffff] + TVw[t.y >> 16];
+            }
+            *reinterpret_cast<double2*>(G + i0) = o;
         }
     }
 }
