@@ -202,7 +202,11 @@ def main():
     barrier()
     itersBefore = state["iters"]
     state["trace"] = []
-    eng.profileEnable(True)
+    # HIP events around the dominant kernel's launches inside the timed region, on the stream they are
+    # launched on. An event pair keeps a launch from being dispatched back to back with its neighbours
+    # (c3: +12 us per LM round when every launch is bracketed), so every PROF_EVERY-th launch is timed (>= 6 samples).
+    PROF_EVERY = max(1, min(16, args.steps // 6)) if args.lm_mode == "fused" else 1
+    eng.profileEnable(True, every=PROF_EVERY)
     t0 = time.perf_counter()
     runSteps(args.steps)
     barrier()
@@ -295,7 +299,8 @@ def main():
                         "mfma_only_frac": mfmaFlops / (fusedAvgMs * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
                         "points_per_launch": fusedPts,
                         "algorithmic_hbm_bytes_per_launch": 5 * w * fusedPts,
-                        "avg_launch_ms": fusedAvgMs, "launches_timed": fusedN}
+                        "avg_launch_ms": fusedAvgMs, "launches_timed": fusedN,
+                        "timed_every_nth_launch": PROF_EVERY}
         else:
             mainRoof = jacRoof
         out = {

@@ -217,8 +217,10 @@ class RefineEngine:
         return sse.value, P, iters.value, trace[:iters.value]
 
     # ---- profiling -----------------------------------------------------------------------
-    def profileEnable(self, on=True):
-        nat.check(self._lib.calib_profile_enable(self._h, 1 if on else 0))
+    def profileEnable(self, on=True, every=1):
+        """HIP-event timing of the dominant kernels; every = N times only every N-th launch of each
+        kernel (timing all of them slows the loop being measured)."""
+        nat.check(self._lib.calib_profile_enable(self._h, max(1, int(every)) if on else 0))
 
     def profileRead(self, which):
         ms = ctypes.c_double(0.0)

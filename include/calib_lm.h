@@ -170,8 +170,11 @@ int calib_distortion_normal_equations(int model, int64_t num_views, const int64_
                                       const double* W, double* out_DtD, double* out_Dtd, int device_id);
 
 /* HIP-event timing of the dominant kernels over the rounds enqueued since the last
- * calib_profile_enable(h, 1). which: 0 = jacobian kernel, 1 = J^T J (MFMA) kernel,
- * 2 = fused jacobian + J^T J kernel. */
+ * calib_profile_enable(h, on). on = 0: off; on = 1: every launch is bracketed by an event pair;
+ * on = N > 1: every N-th launch of each kernel (an event pair keeps a launch from being dispatched
+ * back to back with its neighbours, so timing every launch slows the loop it measures).
+ * which: 0 = jacobian kernel, 1 = J^T J (MFMA) kernel, 2 = fused jacobian + J^T J kernel;
+ * out_launches = launches timed, out_total_ms = their summed duration. */
 int calib_profile_enable(calib_handle_t h, int on);
 int calib_profile_read(calib_handle_t h, int which, double* out_total_ms, int64_t* out_launches);
 

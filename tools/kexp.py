@@ -19,7 +19,8 @@ eng.setProblem(sh["viewOffsets"], sh["sensorPoints"], sh["modelPoints"])
 eng.lmBegin(sh["P0"], a.steps + 10, lamMin=0.0, lamMax=float("inf"), errMin=-float("inf"))
 eng.lmRun(4)
 eng.lmDone()
-eng.profileEnable(True)
+if not os.environ.get("KEXP_NOPROF"):
+    eng.profileEnable(True)
 import time
 t0 = time.perf_counter()
 eng.lmRun(a.steps)
