@@ -296,3 +296,27 @@ def test_whole_pipeline_at_scale_vs_c_oracle():
     assert np.max(np.abs(tr[:n, 1] - trO[:n, 1]) / trO[:n, 1]) < 1e-9
     assert np.abs(P - PO).max() < 1e-7
     eng.close()
+
+
+def test_sampled_event_timing_counts_every_nth_launch():
+    """calib_profile_enable(h, N): only every N-th launch of a kernel is bracketed by HIP events (what
+    bench.py uses inside its timed region), and the results of the run do not depend on it."""
+    sh = synthetic.makeShard("c2", numViews=200, noiseSigma=0.0)
+    offs, s, m = sh["viewOffsets"], sh["sensorPoints"], sh["modelPoints"]
+    outs = []
+    for every in (0, 1, 4):
+        eng = cca.RefineEngine("radtan")
+        eng.setProblem(offs, s, m)
+        eng.lmBegin(sh["P0"], 16, lamMin=0.0, lamMax=float("inf"), errMin=-float("inf"))
+        if every:
+            eng.profileEnable(True, every=every)
+        eng.lmRun(16)
+        eng.lmDone()
+        if every:
+            ms, n = eng.profileRead(2)
+            assert n == 16 // every and ms > 0.0
+            assert eng.profileRead(0)[1] == 0              # fused mode: no jacobian / gram launches
+        outs.append(eng.lmEnd())
+        eng.close()
+    for o in outs[1:]:
+        assert o[0] == outs[0][0] and np.array_equal(o[1], outs[0][1])
