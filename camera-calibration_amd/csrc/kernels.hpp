@@ -253,8 +253,9 @@ __global__ __launch_bounds__(256) void gram_kernel(const typename Pair<T>::type*
     __shared__ double sred[4][kGStride];
     if (sel && st->done) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sub = wave % wpi;
-    const int item = item_begin + blockIdx.x * (4 / wpi) + wave / wpi;
+    const int lw = wpi == 4 ? 2 : (wpi == 2 ? 1 : 0);           // wpi is 1, 2 or 4
+    const int sub = wave & (wpi - 1);
+    const int item = item_begin + blockIdx.x * (4 >> lw) + (wave >> lw);
     const bool valid = item < item_end;
     const int c = lane & 15, k = lane >> 4;
     const bool cvalid = c < C;
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const typename Pair<T>::type*
         const int64_t pbeg = item_pt0[item] - j_origin, pend = pbeg + item_n[item];
         const T2* rq = r + j_origin;
         const int64_t grp0 = pbeg >> 2, grp1 = (pend + 3) >> 2;
-        const int per = (int)((grp1 - grp0 + wpi - 1) / wpi);
+        const int per = (int)((grp1 - grp0 + wpi - 1) >> lw);
         const int64_t gb = grp0 + (int64_t)sub * per;
         const int64_t ge = gb + per < grp1 ? gb + per : grp1;
         const int chunk = lane < 4 * C ? lane : 4 * C - 1;
@@ -370,8 +371,9 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
     const double* P = selectP(P0, P1, st, sel);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int sub = wave % wpi;
-    const int item = blockIdx.x * (WAVES / wpi) + wave / wpi;
+    const int lw = wpi == 4 ? 2 : (wpi == 2 ? 1 : 0);           // wpi is 1, 2 or 4: shifts, not divisions
+    const int sub = wave & (wpi - 1);
+    const int item = blockIdx.x * (WAVES >> lw) + (wave >> lw);
     const bool valid = item < n_items;
     const int c = lane & 15, k = lane >> 4;
     T2* slab = reinterpret_cast<T2*>(smem) + wave * SLAB;
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
     if (valid) {
         const int64_t pbeg = item_pt0[item];
         const int n = item_n[item];
-        const int per = ((n + 3) / 4 + wpi - 1) / wpi * 4;      // points per wave, multiple of 4
+        const int per = ((((n + 3) >> 2) + wpi - 1) >> lw) << 2;    // points per wave, multiple of 4
         const int qbeg = sub * per;
         const int qend = qbeg + per < n ? qbeg + per : n;
         const T* vc = VC + (int64_t)__builtin_amdgcn_readfirstlane(item_view[item]) * kViewStride;
