@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const typename Pair<T>::type*
 // in registers), transposes 32 points at a time through its private LDS slab (rows padded to an
 // odd number of 16-B chunks: conflict-free ds_write_b128 / ds_read_b128) into the MFMA operand
 // map (lane (k, c) <- point 4s+k, column c) and feeds v_mfma_f64_16x16x4_f64. The view constants
-// are wave-uniform (scalar loads). HBM traffic per point: the 44 B of inputs.
+// are wave-uniform (scalar loads). HBM traffic per point: the 40 B of inputs (5 values of width w).
 constexpr int kFusedRowChunks = 17;                       // 16 columns + 1 pad chunk (odd => conflict-free)
 
 // ROWS = points transposed per LDS pass (32: two passes per 64-point batch, half the lanes
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
 }
 
 // ---------------------------------------------------------------- per-view elimination
-// 16 lanes per view; lane c owns column c of the view's symmetric 16x16 Gram.
+// 16 lanes per view, working from the head of the view's record(s): lane c < L owns row c of E, lane L the view gradient.
 __device__ __forceinline__ constexpr int tri(int m, int n) { return m * (m + 1) / 2 + n; }
 
 // 1/sqrt(d) for the Cholesky pivots: v_rsq_f64 seed (~2^-26 relative) and two Newton steps -- a
