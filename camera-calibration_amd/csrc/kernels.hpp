@@ -810,14 +810,54 @@ __device__ __forceinline__ bool gauss_jordan16(double (&row)[N + 1], int i, int&
     return singular;
 }
 
+// ---------------------------------------------------------------- SPD solve on lanes 0..15 of a wave
+// S x = s for a symmetric positive definite S (the damped Schur complement of an SPD system is
+// SPD); lane i owns row i of [S | s]. Gaussian elimination without pivoting -- backward stable for
+// SPD matrices -- so the pivot row is a compile-time lane and its broadcast a v_readlane: no pivot
+// search, no division per row (the 10 x 10 Gauss-Jordan with pivot search took 5 of the update
+// kernel's 9-13 us). Every lane returns the whole solution. Returns false when a pivot is not
+// positive; the caller then falls back to gauss_jordan16 (same behaviour as before on such input).
+// Only valid in lanes 0..15 of a wave with the other lanes inactive.
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+template <int N>
+__device__ __forceinline__ bool spd_solve_wave0(double (&row)[N + 1], int i, double (&x)[N]) {
+    bool ok = true;
+    double rinv[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double p[N + 1];
+#pragma unroll
+        for (int k = j; k <= N; ++k) p[k] = readlane_d(row[k], j);
+        if (!(p[j] > 0.0)) ok = false;
+        rinv[j] = div_nr(1.0, p[j]);
+        if (i > j) {
+            const double f = row[j] * rinv[j];
+#pragma unroll
+            for (int k = j + 1; k <= N; ++k) row[k] -= f * p[k];
+        }
+    }
+    double acc = row[N];                                 // back substitution, U x = y
+#pragma unroll
+    for (int j = N - 1; j >= 0; --j) {
+        const double xj = readlane_d(acc, j) * rinv[j];
+        x[j] = xj;
+        if (i < j) acc -= row[j] * xj;
+    }
+    return ok;
+}
+
 // ---------------------------------------------------------------- update (16 lanes, device function)
 // The control flow of src/calibrate.py:155-168 and the L x L solve S dc = s of the shared block.
 // The LM state is double-buffered per round (in: this round's, out: next round's), so EVERY
 // 16-lane group of the update kernel below can run this redundantly from the same inputs and
 // reach the same decision with no grid-wide hand-off; only the `writer` group stores the new
-// state, the trace row and the shared part of the next candidate. Lane i owns row i of [S | s];
-// Gauss-Jordan with partial pivoting across lanes (np.linalg.inv in the reference is LU with
-// partial pivoting too). Returns false when the loop is over (nothing left to back-substitute).
+// state, the trace row and the shared part of the next candidate. Lane i owns row i of [S | s]:
+// spd_solve_wave0, with Gauss-Jordan and partial pivoting across lanes as the fallback
+// (np.linalg.inv in the reference is LU with partial pivoting). Returns false when the loop is over (nothing left to back-substitute).
 template <int L>
 __device__ __forceinline__ bool lm_update_step(const LMState* __restrict__ in, LMState* __restrict__ out,
                                                const double* __restrict__ red, double* __restrict__ P0,
@@ -886,11 +926,21 @@ __device__ __forceinline__ bool lm_update_step(const LMState* __restrict__ in, L
 #pragma unroll
         for (int j = 0; j < L; ++j) if (j == i) row[j] += lam * brow[j];
     }
-    int myCol = -1;
-    double d = 0.0;
-    if (!done && gauss_jordan16<L, true>(row, i, myCol, d)) { error = -3; done = true; }
+    if (!done) {
+        double saved[L + 1];
 #pragma unroll
-    for (int c = 0; c < L; ++c) dc[c] = group_sum16(myCol == c ? d : 0.0);
+        for (int j = 0; j <= L; ++j) saved[j] = row[j];
+        if (!spd_solve_wave0<L>(row, i, dc)) {           // not positive definite to working precision
+            int myCol = -1;
+            double d = 0.0;
+            if (gauss_jordan16<L, true>(saved, i, myCol, d)) { error = -3; done = true; }
+#pragma unroll
+            for (int c = 0; c < L; ++c) dc[c] = group_sum16(myCol == c ? d : 0.0);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < L; ++c) dc[c] = 0.0;
+    }
 
     if (writer) {
         if (i < L) {
