@@ -84,7 +84,8 @@ struct calib_handle_s {
     DevBuf<uint32_t> emit_tab;    // fused kernel's record assembly table (buildEmitTable)
     int lm_mode = CALIB_LM_FUSED;
     DevBuf<int64_t> item_pt0;
-    DevBuf<double> sse_part, G[2], part, red_own, P[2], Peval, trace;
+    DevBuf<double> sse_part, G[2], bpart, part, red_own, P[2], Peval, trace;
+    int n_bpart = 0;              // workgroup partials of the shared block written by this round's pass
     DevBuf<LMState> st, st_eval;
     double* red = nullptr;        // active reduce buffer (own or bound)
     bool lm_active = false;
@@ -186,8 +187,9 @@ int launch_gram_t(calib_handle_s* h, const LMState* st, int sel, int item0, int 
     hipLaunchKernelGGL((gram_kernel<T, C>), dim3(blocks), dim3(256), 0, h->stream,
                        reinterpret_cast<const T2*>(h->J.p), reinterpret_cast<const T2*>(h->r.p),
                        h->item_pt0.p, h->item_n.p, item0, item1, origin, h->gram_wpi, st, sel, h->G[0].p,
-                       h->G[1].p);
+                       h->G[1].p, h->bpart.p, h->n_bpart);
     prof_end(h, pi);
+    h->n_bpart += blocks;                  // the chunk's workgroups append their partials
     HIP_TRY(hipGetLastError());
     return CALIB_OK;
 }
@@ -212,8 +214,10 @@ int launch_fused_t(calib_handle_s* h, const LMState* st, int sel) {
     hipLaunchKernelGGL((fused_kernel<MODEL, T, 32, 4>), dim3(blocks), dim3(256), 0, h->stream, h->P[0].p,
                        h->P[1].p, reinterpret_cast<const T2*>(h->uv.p), reinterpret_cast<const T2*>(h->XY.p),
                        reinterpret_cast<const T*>(h->Z.p), reinterpret_cast<const T*>(h->VC.p), h->item_pt0.p,
-                       h->item_n.p, h->item_view.p, h->n_items, wpi, h->emit_tab.p, st, sel, h->G[0].p, h->G[1].p);
+                       h->item_n.p, h->item_view.p, h->n_items, wpi, h->emit_tab.p, st, sel, h->G[0].p, h->G[1].p,
+                       h->bpart.p);
     prof_end(h, pi);
+    h->n_bpart = blocks;
     HIP_TRY(hipGetLastError());
     return CALIB_OK;
 }
@@ -235,10 +239,10 @@ int launch_schur_reduce(calib_handle_s* h, const LMState* st, double* red) {
         dim3 grid(h->schur_blocks, 3);
         if (h->L == 10)
             hipLaunchKernelGGL((schur_kernel<10>), grid, dim3(kSchurBlock), 0, h->stream, h->G[0].p,
-                               h->G[1].p, st, view_items(h), h->nv, h->n_items, h->part.p);
+                               h->G[1].p, st, view_items(h), h->nv, h->bpart.p, h->n_bpart, h->part.p);
         else
             hipLaunchKernelGGL((schur_kernel<9>), grid, dim3(kSchurBlock), 0, h->stream, h->G[0].p,
-                               h->G[1].p, st, view_items(h), h->nv, h->n_items, h->part.p);
+                               h->G[1].p, st, view_items(h), h->nv, h->bpart.p, h->n_bpart, h->part.p);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(reduce_kernel, dim3(2 * VA), dim3(64), 0, h->stream, h->part.p,
@@ -323,9 +327,9 @@ int calib_create(int model, int dtype, int device_id, calib_handle_t* out_handle
     }
     h->stream = h->own_stream;
     {
-        uint32_t tab[kGStride];
+        uint32_t tab[kEmitTabSize];
         buildEmitTable(h->C, tab);
-        e = h->emit_tab.alloc(kGStride);
+        e = h->emit_tab.alloc(kEmitTabSize);
         if (e == hipSuccess) e = hipMemcpy(h->emit_tab.p, tab, sizeof(tab), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             h->emit_tab.release();
@@ -348,7 +352,7 @@ int calib_destroy(calib_handle_t h) {
     h->r.release(); h->y.release(); h->pt_view.release(); h->view_ext.release();
     h->item_n.release(); h->view_item0.release(); h->item_view.release(); h->item_pt0.release(); h->sse_part.release();
     h->emit_tab.release();
-    h->G[0].release(); h->G[1].release(); h->part.release(); h->red_own.release();
+    h->G[0].release(); h->G[1].release(); h->bpart.release(); h->part.release(); h->red_own.release();
     h->P[0].release(); h->P[1].release(); h->Peval.release(); h->trace.release();
     h->st.release(); h->st_eval.release();
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -610,6 +614,7 @@ int calib_lm_begin(calib_handle_t h, const double* P0, int max_iters, double lam
         HIP_TRY(h->J.alloc((size_t)((h->max_chunk_points + 3) / 4 * 4) * h->C * 2 * ts));
     HIP_TRY(h->G[0].alloc((size_t)std::max(h->n_items, 1) * kGStride));
     HIP_TRY(h->G[1].alloc((size_t)std::max(h->n_items, 1) * kGStride));
+    HIP_TRY(h->bpart.alloc(((size_t)std::max(h->n_items, 1) + h->chunks.size()) * kPartStride));   // <= 1 per item (+1 per chunk)
     HIP_TRY(h->part.alloc((size_t)2 * h->schur_blocks * variantSize(h->L)));
     HIP_TRY(h->red_own.alloc((size_t)reduceSize(h->L)));
     if (!h->red) h->red = h->red_own.p;
@@ -648,6 +653,7 @@ int calib_lm_local(calib_handle_t h) {
         if (rc) return rc;
         return launch_schur_reduce(h, st, h->red);
     }
+    h->n_bpart = 0;
     for (const auto& c : h->chunks) {
         rc = launch_jacobian(h, h->P[0].p, h->P[1].p, st, 1, true, true, false, false, c.p0, c.p1);
         if (rc) return rc;

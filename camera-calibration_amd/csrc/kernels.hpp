@@ -18,42 +18,31 @@ namespace calib {
 constexpr int kTile = 256;        // points per jacobian workgroup
 constexpr int kGramChunk = 512;   // points per gram work item (one wave)
 constexpr int kGramUnroll = 4;    // 4-point groups (1 KiB wave-loads of J) in flight per trip
-// Per-item normal-equation record. With the parameter order (L shared, 6 view) the 16x16 tile
-// G = J^T J splits into B = G[0:L, 0:L] and the six view rows R = G[L:L+6, 0:16] = [E^T | V | 0]; the
-// record keeps R first, then g = J^T r and sum r^2, then B, so the kernels that only eliminate the
-// view block (variant B of schur_kernel, update_backsub_kernel) read the leading kGHead doubles.
+// Normal equations of one pass over the points. With the parameter order (L shared, 6 view) the
+// 16x16 tile G = J^T J of a view item splits into the shared block B = G[0:L, 0:L] and the six view
+// rows R = G[L:L+6, 0:16] = [E^T | V | 0] (the E block above the diagonal is R's transpose).
+// * Per item, a 1 KiB record: R, then g = J^T r, then sum r^2 -- all the per-view elimination reads.
+// * Per workgroup of the kernel that forms them (4 waves = up to 4 items), one partial of what is
+//   only ever needed summed over all views: B, g_c = g[0:L], sum r^2.
 constexpr int kGRows = 0;         // R[m][c] at m * 16 + c
 constexpr int kGg = 96;           // g[c]
 constexpr int kGSse = 112;        // sum r^2
 constexpr int kGHead = 113;
-constexpr int kGB = 120;          // B[r][c] at kGB + r * L + c
-constexpr int kGStride = 224;     // doubles per item (1792 B)
+constexpr int kGStride = 128;     // doubles per item record (1 KiB)
+constexpr int kPartStride = 112;  // doubles per workgroup partial: B (L*L), g_c (L), sum r^2
 constexpr int kMaxL = 10;
 
-// slot of tile entry (row, col) in the record, -1 when the entry is not kept (the E block above the
-// diagonal is the transpose of R's leading columns; row / column 15 of a 15-column model is zero)
-template <int L>
-__device__ __forceinline__ int gSlot(int row, int col) {
-    if (row >= L && row < L + 6) return kGRows + (row - L) * 16 + col;
-    if (row < L && col < L) return kGB + row * L + col;
-    return -1;
-}
-template <int L>
-__device__ __forceinline__ void gPut(double* dst, int row, int col, double val) {
-    const int s = gSlot<L>(row, col);
-    if (s >= 0) dst[s] = val;
-}
-__device__ __forceinline__ bool gLive(int i, int L) { return i < kGHead || (i >= kGB && i < kGB + L * L); }
-
-// Fused kernel: how record slot i is assembled from the two accumulator tiles of a wave (TU: the u
+// Fused kernel: how an output slot is assembled from the two accumulator tiles of a wave (TU: the u
 // rows of J, TV: the v rows): slot i = TU[tab[i] & 0xffff] + TV[tab[i] >> 16], tile index row * 16 +
 // col, kEmitZero = "nothing". Fisheye (C = 15): the residual rides in MFMA column 15, so both tiles
 // are plain J^T J with J^T r in row 15 and sum r^2 in the corner. Radial-tangential (C = 16):
 // J's constant columns 3 and 4, (1,0) and (0,1), are replaced by one column of (1,1) -- TU[.][3] =
 // sum Ju, TV[.][3] = sum Jv -- and column 4 carries the residual (see fused_kernel).
+// tab[0 .. kGStride) describes the item record, tab[kGStride .. kGStride + kPartStride) the partial.
 constexpr int kEmitZero = 256;
 constexpr int kEmitTile = 264;        // doubles per tile in LDS: 256 + the zero slot, padded
-inline void buildEmitTable(int C, uint32_t* tab /* kGStride */) {
+constexpr int kEmitTabSize = kGStride + kPartStride;
+inline void buildEmitTable(int C, uint32_t* tab /* kEmitTabSize */) {
     const int L = C - 6;
     const auto both = [](int idx) { return (uint32_t)idx | ((uint32_t)idx << 16); };
     const auto pick = [](int iu, int iv) { return (uint32_t)iu | ((uint32_t)iv << 16); };
@@ -68,16 +57,22 @@ inline void buildEmitTable(int C, uint32_t* tab /* kGStride */) {
         if (row != col) return both(Z);                                                  // (1,0).(0,1) = 0
         return row == 3 ? pick(3 * 16 + 3, Z) : pick(Z, 3 * 16 + 3);                     // point count
     };
-    for (int i = 0; i < kGStride; ++i) tab[i] = both(Z);
+    // entry c of J^T r, and sum r^2
+    const auto gentry = [&](int c) -> uint32_t {
+        if (C == 15) return both(15 * 16 + c);
+        return c == 3 ? pick(3 * 16 + 4, Z) : (c == 4 ? pick(Z, 3 * 16 + 4) : both(c * 16 + 4));
+    };
+    const uint32_t sse = C == 15 ? both(15 * 16 + 15) : both(4 * 16 + 4);
+    for (int i = 0; i < kEmitTabSize; ++i) tab[i] = both(Z);
     for (int m = 0; m < 6; ++m)
         for (int c = 0; c < 16; ++c) tab[kGRows + m * 16 + c] = entry(L + m, c);
+    for (int c = 0; c < C; ++c) tab[kGg + c] = gentry(c);
+    tab[kGSse] = sse;
+    uint32_t* part = tab + kGStride;
     for (int r = 0; r < L; ++r)
-        for (int c = 0; c < L; ++c) tab[kGB + r * L + c] = entry(r, c);
-    for (int c = 0; c < C; ++c) {
-        if (C == 15) tab[kGg + c] = both(15 * 16 + c);
-        else tab[kGg + c] = c == 3 ? pick(3 * 16 + 4, Z) : (c == 4 ? pick(Z, 3 * 16 + 4) : both(c * 16 + 4));
-    }
-    tab[kGSse] = C == 15 ? both(15 * 16 + 15) : both(4 * 16 + 4);
+        for (int c = 0; c < L; ++c) part[r * L + c] = entry(r, c);
+    for (int c = 0; c < L; ++c) part[L * L + c] = gentry(c);
+    part[L * L + L] = sse;
 }
 
 // Compact Jacobian in HBM: groups of 4 points, [group][column][point-in-group] of (du, dv) pairs.
@@ -248,9 +243,11 @@ __global__ __launch_bounds__(256) void gram_kernel(const typename Pair<T>::type*
                                                    const int* __restrict__ item_n, int item_begin,
                                                    int item_end, int64_t j_origin, int wpi,
                                                    const LMState* __restrict__ st, int sel,
-                                                   double* __restrict__ G0, double* __restrict__ G1) {
+                                                   double* __restrict__ G0, double* __restrict__ G1,
+                                                   double* __restrict__ part, int part_base) {
     using T2 = typename Pair<T>::type;
-    __shared__ double sred[4][kGStride];
+    constexpr int L = C - 6;
+    __shared__ double stile[4][256 + 16 + 8];   // per wave: tile, J^T r, sum r^2
     if (sel && st->done) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lw = wpi == 4 ? 2 : (wpi == 2 ? 1 : 0);           // wpi is 1, 2 or 4
@@ -306,27 +303,30 @@ __global__ __launch_bounds__(256) void gram_kernel(const typename Pair<T>::type*
         eacc += __shfl_xor(eacc, 32, 64);
     }
     double* Gbase = sel ? ((st->cur ^ 1) ? G1 : G0) : G0;
-    // f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
-    if (wpi == 1) {
-        if (!valid) return;
-        double* G = Gbase + (int64_t)item * kGStride;
+    // every wave parks its tile (f64 MFMA C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg;
+    // zeros for a wave without an item), J^T r and sum r^2 in LDS
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) gPut<C - 6>(G, k + 4 * reg, c, acc[reg]);
-        if (k == 0) G[kGg + c] = gacc;
-        if (lane == 0) G[kGSse] = eacc;         // sum over the item's points of |r|^2
-        return;
-    }
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) gPut<C - 6>(sred[wave], k + 4 * reg, c, acc[reg]);
-    if (k == 0) sred[wave][kGg + c] = gacc;
-    if (lane == 0) sred[wave][kGSse] = eacc;
+    for (int reg = 0; reg < 4; ++reg) stile[wave][(k + 4 * reg) * 16 + c] = acc[reg];
+    if (k == 0) stile[wave][256 + c] = gacc;
+    if (lane == 0) stile[wave][272] = eacc;
     __syncthreads();
-    if (sub == 0 && valid) {                    // the item's first wave sums the partials in wave order
+    // the workgroup's partial of the shared block (fixed wave order)
+    if (threadIdx.x < L * L + L + 1) {
+        const int t = threadIdx.x;
+        const int idx = t < L * L ? (t / L) * 16 + t % L : (t < L * L + L ? 256 + (t - L * L) : 272);
+        part[(int64_t)(part_base + blockIdx.x) * kPartStride + t] =
+            (stile[0][idx] + stile[1][idx]) + (stile[2][idx] + stile[3][idx]);
+    }
+    // the item's record: its first wave sums the item's partial tiles in wave order
+    if (sub == 0 && valid) {
         double* G = Gbase + (int64_t)item * kGStride;
         for (int i = lane; i < kGStride; i += 64) {
-            if (!gLive(i, C - 6)) continue;
-            double t = sred[wave][i];
-            for (int w = 1; w < wpi; ++w) t += sred[wave + w][i];
+            const int idx = i < 96 ? (L + i / 16) * 16 + i % 16 : (i < 112 ? 256 + (i - 96) : 272);
+            double t = 0.0;
+            if (i < kGHead) {
+                t = stile[wave][idx];
+                for (int w = 1; w < wpi; ++w) t += stile[wave + w][idx];
+            }
             G[i] = t;
         }
     }
@@ -353,7 +353,8 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
                                                     const int* __restrict__ item_view, int n_items, int wpi,
                                                     const uint32_t* __restrict__ emit_tab,
                                                     const LMState* __restrict__ st, int sel,
-                                                    double* __restrict__ G0, double* __restrict__ G1) {
+                                                    double* __restrict__ G0, double* __restrict__ G1,
+                                                    double* __restrict__ part) {
     using T2 = typename Pair<T>::type;
     constexpr int C = ModelTraits<MODEL>::C;
     constexpr int RS = kFusedRowChunks;
@@ -462,41 +463,48 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
             }
         }
     }
-    // Record assembly: the wave parks its two accumulator tiles (f64 MFMA C/D layout: col = lane & 15,
-    // row = (lane >> 4) + 4 * reg) in its dead slab, then every lane builds two adjacent record slots
-    // per pass from the table -- no case analysis, two 1 KiB-coalesced stores per item.
+    // Output assembly: every wave parks its two accumulator tiles (f64 MFMA C/D layout: col = lane & 15,
+    // row = (lane >> 4) + 4 * reg; zeros for a wave without an item) in its dead slab; then the
+    // workgroup writes its partial of the shared block and each item's first wave the item's record,
+    // both from the index table -- no case analysis, 16-byte coalesced stores.
     static_assert(SLAB * sizeof(T2) >= 2 * kEmitTile * 8, "tiles must fit the wave's slab");
     double* TU = reinterpret_cast<double*>(slab);
     double* TV = TU + kEmitTile;
     double* Gbase = sel ? ((st->cur ^ 1) ? G1 : G0) : G0;
-    if (wpi > 1) __syncthreads();                               // partner waves may still read their slabs
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();                                            // partner waves may still read their slabs
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         TU[(k + 4 * reg) * 16 + c] = acc[reg];
         TV[(k + 4 * reg) * 16 + c] = acc2[reg];
     }
     if (lane == 0) { TU[kEmitZero] = 0.0; TV[kEmitZero] = 0.0; }
-    if (wpi > 1) __syncthreads();
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    if ((int)threadIdx.x < kPartStride) {                       // partial of B, g_c, sum r^2: all waves, wave order
+        const uint32_t t = emit_tab[kGStride + threadIdx.x];
+        const double* T0 = reinterpret_cast<const double*>(smem);
+        double o = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const double* TUw = reinterpret_cast<const double*>(reinterpret_cast<const T2*>(T0) + w * SLAB);
+            o += TUw[t & 0xffff] + (TUw + kEmitTile)[t >> 16];
+        }
+        part[(int64_t)blockIdx.x * kPartStride + threadIdx.x] = o;
+    }
     if (sub != 0 || !valid) return;                             // the item's first wave assembles the record
     double* G = Gbase + (int64_t)item * kGStride;
-#pragma unroll
-    for (int pass = 0; pass < (kGStride + 127) / 128; ++pass) {
-        const int i0 = 128 * pass + 2 * lane;
-        if (i0 < kGStride) {
-            const uint2 t = *reinterpret_cast<const uint2*>(emit_tab + i0);
-            double2 o;
-            o.x = TU[t.x & 0xffff] + TV[t.x >> 16];
-            o.y = TU[t.y & 0xffff] + TV[t.y >> 16];
-            for (int w = 1; w < wpi; ++w) {                     // partial tiles of the item's other waves, in wave order
-                const double* TUw = reinterpret_cast<const double*>(slab + w * SLAB);
-                const double* TVw = TUw + kEmitTile;
-                o.x += TUw[t.x & 0xffff] + TVw[t.x >> 16];
-                o.y += TUw[t.y & 0xffff] + TVw[t.y >> 16];
-            }
-            *reinterpret_cast<double2*>(G + i0) = o;
+    {
+        const int i0 = 2 * lane;                                // kGStride = 128: one pass
+        const uint2 t = *reinterpret_cast<const uint2*>(emit_tab + i0);
+        double2 o;
+        o.x = TU[t.x & 0xffff] + TV[t.x >> 16];
+        o.y = TU[t.y & 0xffff] + TV[t.y >> 16];
+        for (int w = 1; w < wpi; ++w) {                         // partial tiles of the item's other waves, in wave order
+            const double* TUw = reinterpret_cast<const double*>(slab + w * SLAB);
+            const double* TVw = TUw + kEmitTile;
+            o.x += TUw[t.x & 0xffff] + TVw[t.x >> 16];
+            o.y += TUw[t.y & 0xffff] + TVw[t.y >> 16];
         }
+        *reinterpret_cast<double2*>(G + i0) = o;
     }
 }
 
@@ -575,7 +583,7 @@ __device__ __forceinline__ bool eliminate(double (&V)[21], const double (&b)[6],
 // ---------------------------------------------------------------- schur partials
 // grid (nblocks, 3): y = 0 variant A (candidate blocks, lambda_accept),
 //                    y = 1 variant B (current blocks, lambda_reject),
-//                    y = 2 plain sums over the candidate's items: B, g_c, sum r^2 (variant A's fields).
+//                    y = 2 plain sums of the workgroup partials of B, g_c, sum r^2 (variant A's fields).
 // Elimination (y < 2): 16 lanes per view, 4 views per wave and trip, reading only the head of the
 // view's record. Every lane factors the view's damped 6x6 block Vh = Lc Lc^T (loaded by broadcast),
 // lane c < L forward-substitutes its row of E (z_c = Lc^-1 E_c), lane L the view gradient
@@ -589,7 +597,8 @@ __global__ __launch_bounds__(kSchurBlock) void schur_kernel(const double* __rest
                                                             const double* __restrict__ G1,
                                                             const LMState* __restrict__ st,
                                                             const int* __restrict__ view_item0,
-                                                            int nv, int n_items, double* __restrict__ part) {
+                                                            int nv, const double* __restrict__ bpart,
+                                                            int n_bpart, double* __restrict__ part) {
     constexpr int VA = variantSize(L);
     constexpr int kNfail = 2 * L * L + 2 * L, kSse = kNfail + 1;
     __shared__ double sfail[kSchurViewsPerBlock];
@@ -601,24 +610,22 @@ __global__ __launch_bounds__(kSchurBlock) void schur_kernel(const double* __rest
     const int cand = st->cur ^ 1;
 
     if (variant == 2) {
-        // thread t of each half-block owns one field of the record; a wave reads 512 contiguous bytes
+        // thread t of each half-block owns one field of the workgroup partials of B, g_c, sum r^2
         constexpr int NF = L * L + L + 1;
         double* out = part + (int64_t)blockIdx.x * VA;
-        const double* G = cand ? G1 : G0;
         const int t = tid & 127, half = tid >> 7;
-        const int field = t < L * L ? kGB + t : (t < L * L + L ? kGg + (t - L * L) : kGSse);
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         if (t < NF) {
             const int64_t step = (int64_t)gridDim.x * 2;
             int64_t it = (int64_t)blockIdx.x * 2 + half;
-            const double* src = G + field;
-            for (; it + 3 * step < n_items; it += 4 * step) {
-                s0 += src[it * kGStride];
-                s1 += src[(it + step) * kGStride];
-                s2 += src[(it + 2 * step) * kGStride];
-                s3 += src[(it + 3 * step) * kGStride];
+            const double* src = bpart + t;
+            for (; it + 3 * step < n_bpart; it += 4 * step) {
+                s0 += src[it * kPartStride];
+                s1 += src[(it + step) * kPartStride];
+                s2 += src[(it + 2 * step) * kPartStride];
+                s3 += src[(it + 3 * step) * kPartStride];
             }
-            for (; it < n_items; it += step) s0 += src[it * kGStride];
+            for (; it < n_bpart; it += step) s0 += src[it * kPartStride];
         }
         double* sh = &stile[0][0];
         sh[tid] = (s0 + s1) + (s2 + s3);
