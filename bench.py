@@ -199,6 +199,9 @@ def main():
             state["trace"].append(tr_)
 
     runSteps(args.warmup)
+    import gc
+    gc.collect()
+    gc.disable()              # no collector pauses inside the timed region (ranks wait for the slowest each round)
     barrier()
     itersBefore = state["iters"]
     state["trace"] = []
@@ -211,6 +214,7 @@ def main():
     runSteps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     jacMs, jacN = eng.profileRead(0)
     gramMs, gramN = eng.profileRead(1)
     fusedMs, fusedN = eng.profileRead(2)
