@@ -471,7 +471,7 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
     double* TU = reinterpret_cast<double*>(slab);
     double* TV = TU + kEmitTile;
     double* Gbase = sel ? ((st->cur ^ 1) ? G1 : G0) : G0;
-    __syncthreads();                                            // partner waves may still read their slabs
+    __builtin_amdgcn_wave_barrier();                            // the slab is this wave's own: no workgroup barrier needed yet
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         TU[(k + 4 * reg) * 16 + c] = acc[reg];
