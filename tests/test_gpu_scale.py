@@ -320,3 +320,41 @@ def test_sampled_event_timing_counts_every_nth_launch():
         eng.close()
     for o in outs[1:]:
         assert o[0] == outs[0][0] and np.array_equal(o[1], outs[0][1])
+
+
+@pytest.mark.parametrize("tag,dtype,views,tolRecover", [("c4", "f32", 100000, 1e-6), ("c5", "f64", 125000, 1e-9)])
+def test_c4_full_and_c5_shard_sizes_properties(tag, dtype, views, tolRecover):
+    """configs[3] at its full size (100 000 views x 54 pts, fp32 storage: 5.4 M correspondences) and
+    configs[4]'s per-GPU shard (125 000 views x 88 pts: 11 M) through size-independent properties on
+    noise-free data: the error at the generating parameters is (numerically) zero, every accepted
+    step lowers the error, lambda follows the /10 - x10 rule, the generating intrinsics are recovered
+    from the perturbed start, and shard sums are additive (two half-shards' normal equations add up)."""
+    cfg = dict(synthetic.CONFIGS[tag])
+    sh = synthetic.makeShard(cfg, numViews=views, noiseSigma=0.0)
+    offs, s, m, Ptrue, P0 = sh["viewOffsets"], sh["sensorPoints"], sh["modelPoints"], sh["Ptrue"], sh["P0"]
+    L, MN = 10, int(offs[-1])
+    eng = cca.RefineEngine("radtan", dtype)
+    eng.setProblem(offs, s, m)
+    sse0 = eng.evaluate(Ptrue)["sse"]
+    assert sse0 < (1e-6 if dtype == "f32" else 1e-18) * MN
+    sse, P, iters, trace = eng.refine(P0, 40)
+    acc = trace[:, 4] == 1
+    assert acc.sum() >= 3 and np.all(trace[acc, 2] < trace[acc, 1])          # accepted => strictly lower error
+    lam = trace[:, 3]
+    assert np.all(np.isclose(lam[1:], np.where(acc[:-1], lam[:-1] / 10, lam[:-1] * 10), rtol=1e-12))
+    assert relIntr(P, Ptrue, L) < tolRecover, relIntr(P, Ptrue, L)
+    # additivity of the shared block over a split of the views (what the all-reduce relies on)
+    B, E, V, g = eng.normalEquations(P0)
+    eng.close()
+    half = views // 2
+    parts = []
+    for v0, v1 in ((0, half), (half, views)):
+        a, b = int(offs[v0]), int(offs[v1])
+        e2 = cca.RefineEngine("radtan", dtype)
+        e2.setProblem(offs[v0:v1 + 1] - a, s[a:b], m[a:b])
+        parts.append(e2.normalEquations(np.concatenate((P0[:L], P0[L + 6 * v0:L + 6 * v1]))))
+        e2.close()
+    Bsum = parts[0][0] + parts[1][0]
+    assert np.abs(Bsum - B).max() <= 1e-12 * np.abs(B).max()
+    assert np.abs(parts[0][3][:L] + parts[1][3][:L] - g[:L]).max() <= 1e-10 * max(np.abs(g[:L]).max(), 1e-300) + 1e-6
+    assert np.array_equal(np.concatenate((parts[0][2], parts[1][2])), V)      # per-view blocks are shard-local
