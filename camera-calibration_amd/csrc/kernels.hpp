@@ -707,8 +707,19 @@ __global__ __launch_bounds__(64) void reduce_kernel(const double* __restrict__ p
     const int i = blockIdx.x, lane = threadIdx.x;
     const int variant = i / VA, idx = i - variant * VA;
     const double* src = part + (int64_t)variant * nblocks * VA + idx;
-    double t = 0.0;
-    for (int b = lane; b < nblocks; b += 64) t += src[(int64_t)b * VA];
+    // all of a lane's loads are issued before the first add (a rolled load-wait-add loop made this
+    // kernel a chain of up to 16 memory latencies); nblocks <= kMaxSchurBlocks = 16 x 64
+    double v[kMaxSchurBlocks / 64];
+#pragma unroll
+    for (int j = 0; j < kMaxSchurBlocks / 64; ++j) {
+        const int b = lane + 64 * j;
+        v[j] = b < nblocks ? src[(int64_t)b * VA] : 0.0;
+    }
+#pragma unroll
+    for (int w = 1; w < kMaxSchurBlocks / 64; w *= 2)
+#pragma unroll
+        for (int j = 0; j + w < kMaxSchurBlocks / 64; j += 2 * w) v[j] += v[j + w];
+    double t = v[0];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
     if (lane == 0) red[i] = t;
