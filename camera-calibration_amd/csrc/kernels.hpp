@@ -896,7 +896,28 @@ __device__ __forceinline__ bool lm_update_step(const LMState* __restrict__ in, L
     const int round = in->round;
     const double err_cand = red[kSse];
     double lam = in->lam;
-    const double* sys = red;
+    // Both candidate systems (variant A in red[0, VA), variant B behind it) and both copies of B, g_c
+    // (variant A's fresh sums, the state's) are requested before the decision is known: one trip to
+    // L2 instead of two dependent ones; the unused half is dropped below.
+    double sA[L], sB[L], bA[L], bS[L];
+    double rhsA = 0.0, rhsB = 0.0, gA = 0.0, gS = 0.0;
+#pragma unroll
+    for (int j = 0; j < L; ++j) { sA[j] = 0.0; sB[j] = 0.0; bA[j] = 0.0; bS[j] = 0.0; }
+    if (i < L) {
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            sA[j] = red[L * L + i * L + j];
+            sB[j] = red[VA + L * L + i * L + j];
+            bA[j] = red[i * L + j];
+            bS[j] = in->B[i * L + j];
+        }
+        rhsA = red[2 * L * L + L + i];
+        rhsB = red[VA + 2 * L * L + L + i];
+        gA = red[2 * L * L + i];
+        gS = in->gc[i];
+    }
+    const double nfailA = red[kNfail], nfailB = red[VA + kNfail];
+    bool useB = false;                               // the reject variant (current blocks, 10 lambda)
     bool done = false;
     double err_cur_new = err_cand, last_err = err_cand;
     int iters = in->iters, accepted = 0;
@@ -911,7 +932,7 @@ __device__ __forceinline__ bool lm_update_step(const LMState* __restrict__ in, L
             if (i < L) row[5 + i] = Pb[cur][i];
             if (i == 0) { row[0] = it; row[1] = err_cur; row[2] = err_cand; row[3] = lam; row[4] = acc ? 1.0 : 0.0; }
         }
-        if (acc) { cur = cand; lam = lam / 10; } else { lam = lam * 10; sys = red + VA; }
+        if (acc) { cur = cand; lam = lam / 10; } else { lam = lam * 10; useB = true; }
         done = !(in->lam_min < lam && lam < in->lam_max) || err_cur < in->err_min || it + 1 >= in->max_iters;
         last_err = err_cur;                          // the reference returns the pre-update error (:155,171)
         err_cur_new = acc ? err_cand : err_cur;
@@ -919,31 +940,22 @@ __device__ __forceinline__ bool lm_update_step(const LMState* __restrict__ in, L
         accepted = acc ? 1 : 0;
     }
     int error = 0;
-    if (!done && sys[kNfail] > 0.0) { error = -3; done = true; }
+    if (!done && (useB ? nfailB : nfailA) > 0.0) { error = -3; done = true; }
 
     // B and g_c of the parameters the step starts from: variant A carries them for a freshly
     // accepted (or the bootstrap) point, which also becomes the state's copy; after a rejection
     // the state's copy of the unchanged current point is used.
-    const bool fresh = sys == red;
-    const double* Bm = fresh ? red : in->B;
-    const double* gcv = fresh ? red + 2 * L * L : in->gc;
     double row[L + 1], brow[L];
-    double gci = 0.0;
+    const double gci = useB ? gS : gA;
+    // row i of S = B + lam diag(B) - sum E Vh^-1 E^T, rhs s = g_c - sum E Vh^-1 g_v (zero rows for i >= L)
 #pragma unroll
-    for (int j = 0; j <= L; ++j) row[j] = 0.0;
-#pragma unroll
-    for (int j = 0; j < L; ++j) brow[j] = 0.0;
-    if (i < L) {
-#pragma unroll
-        for (int j = 0; j < L; ++j) brow[j] = Bm[i * L + j];
-        gci = gcv[i];
-        // row i of S = B + lam diag(B) - sum E Vh^-1 E^T, rhs s = g_c - sum E Vh^-1 g_v
-#pragma unroll
-        for (int j = 0; j < L; ++j) row[j] = brow[j] - sys[L * L + i * L + j];
-        row[L] = gci - sys[2 * L * L + L + i];
-#pragma unroll
-        for (int j = 0; j < L; ++j) if (j == i) row[j] += lam * brow[j];
+    for (int j = 0; j < L; ++j) {
+        brow[j] = useB ? bS[j] : bA[j];
+        row[j] = brow[j] - (useB ? sB[j] : sA[j]);
     }
+    row[L] = gci - (useB ? rhsB : rhsA);
+#pragma unroll
+    for (int j = 0; j < L; ++j) if (j == i) row[j] += lam * brow[j];
     if (!done) {
         double saved[L + 1];
 #pragma unroll
