@@ -245,8 +245,8 @@ def main():
             eng2 = cca.RefineEngine(cfg["model"], cfg["dtype"], local)
             eng2.setProblem(shard["viewOffsets"], shard["sensorPoints"], shard["modelPoints"])
             eng2.setLmMode("two_kernel")
-            eng2.lmBegin(shard["P0"], 16, **lmOpts)
-            eng2.lmRun(4)
+            eng2.lmBegin(shard["P0"], 96, **lmOpts)
+            eng2.lmRun(80)                    # ~25 ms: clocks up again after the upload above (see the spin-up note)
             eng2.lmDone()
             eng2.profileEnable(True)
             t2 = time.perf_counter()
