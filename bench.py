@@ -110,6 +110,11 @@ def main():
     ap.add_argument("--views", type=int, default=None, help="views per GPU (default: the config's)")
     ap.add_argument("--noise", type=float, default=0.1, help="sensor noise sigma in px")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allreduce", choices=["auto", "torch", "direct"], default="torch",
+                    help="the one exchange per LM step at N > 1: 'torch' = torch.distributed.all_reduce (default), "
+                         "'direct' = ncclAllReduce issued by the library on its own stream (self-tested at start-up; "
+                         "so far exercised at world size 1 only), 'auto' = direct when it passes its self-test on "
+                         "every rank, else torch")
     ap.add_argument("--lm-mode", default="fused", choices=["fused", "two_kernel"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
@@ -177,8 +182,17 @@ def main():
     # A segment's bootstrap pass (one extra evaluation of all points) is inside the timed region but
     # not counted as a step.
     SEG = 100
+    allReduceKind = None
     if dist is not None:
-        allReduce = distributed.torchAllReduce(eng, torch.device("cuda", local))
+        allReduce = None
+        if args.allreduce != "torch" and args.backend == "nccl":
+            allReduce = distributed.directAllReduce(eng)
+            if allReduce is None and args.allreduce == "direct":
+                sys.exit("bench.py --allreduce direct: the in-library all-reduce could not be set up")
+        allReduceKind = "ncclAllReduce issued by the library on its own stream" if allReduce is not None \
+            else "torch.distributed.all_reduce"
+        if allReduce is None:
+            allReduce = distributed.torchAllReduce(eng, torch.device("cuda", local))
         lm = distributed.ShardedLM(eng, allReduce)
     state = {"P": shard["P0"], "iters": 0, "trace": [], "sse": float("nan")}
 
@@ -333,7 +347,7 @@ def main():
             "config": {"workload": f"{args.workload}: {viewsPerGpu} views x {shard['pointsPerView']} pts per GPU, "
                                    f"{cfg['model']}, {cfg['dtype']}, sensor noise {args.noise} px",
                        "views_per_gpu": viewsPerGpu, "points_per_view": shard["pointsPerView"],
-                       "global_points": MNglobal, "distortion": cfg["model"], "parallelism": f"views-sharded x{world}",
+                       "global_points": MNglobal, "distortion": cfg["model"], "parallelism": f"views-sharded x{world}", "allreduce": allReduceKind,
                        "lm_mode": args.lm_mode},
             "roofline": mainRoof,
             "roofline_jacobian_kernel": jacRoof,

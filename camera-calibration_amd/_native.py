@@ -61,6 +61,12 @@ SIGNATURES = {
     "calib_distortion_normal_equations": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, _c_int64_p, _c_double_p,
                                                          _c_double_p, _c_double_p, _c_double_p, _c_double_p,
                                                          _c_double_p, ctypes.c_int]),
+    "calib_rccl_load": (ctypes.c_int, [ctypes.c_char_p]),
+    "calib_rccl_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "calib_rccl_init": (ctypes.c_int, [_h, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "calib_rccl_selftest": (ctypes.c_int, [_h, ctypes.c_double]),
+    "calib_rccl_shutdown": (ctypes.c_int, [_h]),
+    "calib_lm_allreduce": (ctypes.c_int, [_h]),
     "calib_profile_enable": (ctypes.c_int, [_h, ctypes.c_int]),
     "calib_profile_read": (ctypes.c_int, [_h, ctypes.c_int, _c_double_p, _c_int64_p]),
 }

@@ -8,6 +8,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <dlfcn.h>
+#include <chrono>
+#include <thread>
 #include <cstring>
 #include <new>
 #include <string>
@@ -88,6 +91,8 @@ struct calib_handle_s {
     int n_bpart = 0;              // workgroup partials of the shared block written by this round's pass
     DevBuf<LMState> st, st_eval;
     double* red = nullptr;        // active reduce buffer (own or bound)
+    void* comm = nullptr;         // RCCL communicator of the in-library all-reduce (calib_rccl_init), or null
+    int comm_ranks = 0, comm_rank = 0;
     bool lm_active = false;
     int lm_max_iters = 0;
     int rounds_enqueued = 0;
@@ -119,6 +124,27 @@ int prof_begin(calib_handle_s* h, int kind) {
 }
 void prof_end(calib_handle_s* h, int idx) {
     if (idx >= 0) (void)hipEventRecord(h->ev[idx + 1], h->stream);
+}
+
+// ---- RCCL, resolved at run time (calib_rccl_load) ------------------------------------------
+// Only the handful of entry points the one all-reduce needs; types as in rccl.h (ncclUniqueId is 128
+// opaque bytes passed by value, ncclDouble = 8, ncclSum = 0, ncclSuccess = 0).
+struct RcclId { char internal[128]; };
+struct RcclApi {
+    void* lib = nullptr;
+    int (*getUniqueId)(RcclId*) = nullptr;
+    int (*commInitRank)(void**, int, RcclId, int) = nullptr;
+    int (*allReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*commDestroy)(void*) = nullptr;
+    int (*commAbort)(void*) = nullptr;
+    const char* (*getErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+constexpr int kNcclDouble = 8, kNcclSum = 0;
+
+int rccl_fail(const char* what, int rc) {
+    return fail(CALIB_E_HIP, std::string(what) + ": " +
+                             (g_rccl.getErrorString ? g_rccl.getErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")");
 }
 
 // ---- launches ---------------------------------------------------------------------------
@@ -347,6 +373,7 @@ int calib_destroy(calib_handle_t h) {
     if (!h) return CALIB_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->comm && g_rccl.commDestroy) { (void)g_rccl.commDestroy(h->comm); h->comm = nullptr; }
     for (auto& e : h->ev) (void)hipEventDestroy(e);
     h->uv.release(); h->XY.release(); h->Z.release(); h->VC.release(); h->J.release();
     h->r.release(); h->y.release(); h->pt_view.release(); h->view_ext.release();
@@ -700,6 +727,10 @@ int calib_lm_run(calib_handle_t h, int rounds, int check_every) {
     for (int i = 0; i < rounds; ++i) {
         int rc = calib_lm_local(h);
         if (rc) return rc;
+        if (h->comm) {
+            rc = calib_lm_allreduce(h);
+            if (rc) return rc;
+        }
         rc = calib_lm_update(h);
         if (rc) return rc;
         if (check_every > 0 && (i + 1) % check_every == 0 && i + 1 < rounds) {
@@ -709,6 +740,109 @@ int calib_lm_run(calib_handle_t h, int rounds, int check_every) {
             if (done) break;
         }
     }
+    return CALIB_OK;
+}
+
+int calib_rccl_load(const char* librccl_path) {
+    if (g_rccl.lib) return CALIB_OK;
+    if (!librccl_path) return fail(CALIB_E_INVALID, "librccl path is null");
+    void* lib = dlopen(librccl_path, RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(CALIB_E_HIP, std::string("dlopen librccl: ") + dlerror());
+    RcclApi a;
+    a.lib = lib;
+    a.getUniqueId = reinterpret_cast<decltype(a.getUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    a.commInitRank = reinterpret_cast<decltype(a.commInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    a.allReduce = reinterpret_cast<decltype(a.allReduce)>(dlsym(lib, "ncclAllReduce"));
+    a.commDestroy = reinterpret_cast<decltype(a.commDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    a.commAbort = reinterpret_cast<decltype(a.commAbort)>(dlsym(lib, "ncclCommAbort"));
+    a.getErrorString = reinterpret_cast<decltype(a.getErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!a.getUniqueId || !a.commInitRank || !a.allReduce || !a.commDestroy || !a.commAbort)
+        return fail(CALIB_E_HIP, "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy / ncclCommAbort");
+    g_rccl = a;
+    return CALIB_OK;
+}
+
+int calib_rccl_unique_id(void* out_id128) {
+    if (!g_rccl.lib) return fail(CALIB_E_STATE, "calib_rccl_load has not been called");
+    if (!out_id128) return fail(CALIB_E_INVALID, "null argument");
+    RcclId id;
+    const int rc = g_rccl.getUniqueId(&id);
+    if (rc) return rccl_fail("ncclGetUniqueId", rc);
+    std::memcpy(out_id128, id.internal, sizeof(id.internal));
+    return CALIB_OK;
+}
+
+int calib_rccl_init(calib_handle_t h, int nranks, int rank, const void* id128) {
+    CHECK_H(h);
+    if (!g_rccl.lib) return fail(CALIB_E_STATE, "calib_rccl_load has not been called");
+    if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(CALIB_E_INVALID, "bad communicator arguments");
+    if (h->comm) return fail(CALIB_E_STATE, "this handle already has a communicator");
+    RcclId id;
+    std::memcpy(id.internal, id128, sizeof(id.internal));
+    void* comm = nullptr;
+    const int rc = g_rccl.commInitRank(&comm, nranks, id, rank);
+    if (rc) return rccl_fail("ncclCommInitRank", rc);
+    h->comm = comm;
+    h->comm_ranks = nranks;
+    h->comm_rank = rank;
+    return CALIB_OK;
+}
+
+int calib_rccl_shutdown(calib_handle_t h) {
+    CHECK_H(h);
+    if (!h->comm) return CALIB_OK;
+    (void)hipStreamSynchronize(h->stream);
+    const int rc = g_rccl.commDestroy(h->comm);
+    h->comm = nullptr;
+    h->comm_ranks = 0;
+    if (rc) return rccl_fail("ncclCommDestroy", rc);
+    return CALIB_OK;
+}
+
+int calib_rccl_selftest(calib_handle_t h, double timeout_s) {
+    CHECK_H(h);
+    if (!h->comm) return fail(CALIB_E_STATE, "calib_rccl_init has not been called");
+    // rank r contributes (r + 1, 1, 2^r, 4): the sums must come back as (n (n + 1) / 2, n, 2^n - 1, 4 n)
+    const int n = h->comm_ranks, r = h->comm_rank;
+    DevBuf<double> buf;
+    HIP_TRY(buf.alloc(4));
+    const double mine[4] = {r + 1.0, 1.0, std::ldexp(1.0, r), 4.0};
+    const double want[4] = {0.5 * n * (n + 1.0), (double)n, std::ldexp(1.0, n) - 1.0, 4.0 * n};
+    hipError_t e = hipMemcpy(buf.p, mine, sizeof(mine), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { buf.release(); return fail(CALIB_E_HIP, hipGetErrorString(e)); }
+    int rc = g_rccl.allReduce(buf.p, buf.p, 4, kNcclDouble, kNcclSum, h->comm, h->stream);
+    if (rc) { buf.release(); return rccl_fail("ncclAllReduce (self-test)", rc); }
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s > 0 ? timeout_s : 30.0);
+    for (;;) {
+        e = hipStreamQuery(h->stream);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) { buf.release(); return fail(CALIB_E_HIP, hipGetErrorString(e)); }
+        if (std::chrono::steady_clock::now() > deadline) {
+            (void)g_rccl.commAbort(h->comm);        // the collective never completed: give the communicator up
+            h->comm = nullptr;
+            h->comm_ranks = 0;
+            return fail(CALIB_E_HIP, "in-library all-reduce self-test timed out");
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    double got[4] = {0, 0, 0, 0};
+    e = hipMemcpy(got, buf.p, sizeof(got), hipMemcpyDeviceToHost);
+    buf.release();
+    if (e != hipSuccess) return fail(CALIB_E_HIP, hipGetErrorString(e));
+    for (int i = 0; i < 4; ++i)
+        if (got[i] != want[i]) {
+            (void)calib_rccl_shutdown(h);
+            return fail(CALIB_E_HIP, "in-library all-reduce self-test returned wrong sums");
+        }
+    return CALIB_OK;
+}
+
+int calib_lm_allreduce(calib_handle_t h) {
+    CHECK_H(h);
+    if (!h->lm_active) return fail(CALIB_E_STATE, "calib_lm_begin has not been called");
+    if (!h->comm) return fail(CALIB_E_STATE, "calib_rccl_init has not been called");
+    const int rc = g_rccl.allReduce(h->red, h->red, (size_t)reduceSize(h->L), kNcclDouble, kNcclSum, h->comm, h->stream);
+    if (rc) return rccl_fail("ncclAllReduce", rc);
     return CALIB_OK;
 }
 

@@ -65,6 +65,10 @@ class ShardedLM:
     def run(self, rounds, checkEvery=0):
         """`rounds` LM iterations; with checkEvery > 0 the (replicated, hence identical on every
         rank) done flag is read every checkEvery rounds and the loop stops early."""
+        if getattr(self.allReduce, "inLibrary", False):
+            # the library all-reduces between its local and update steps itself: whole rounds from C
+            self.eng.lmRun(int(rounds), int(checkEvery))
+            return
         for i in range(int(rounds)):
             self.round()
             if checkEvery > 0 and (i + 1) % checkEvery == 0 and i + 1 < rounds and self.eng.lmDone():
@@ -90,6 +94,60 @@ def torchAllReduce(eng, device):
     return allReduce
 
 
+def directAllReduce(eng, timeoutSeconds=30.0):
+    """Let the engine issue the all-reduce itself (ncclAllReduce on its own stream, RCCL resolved from
+    the librccl.so PyTorch ships and has already loaded): no hand-off to the process group's stream,
+    and whole LM rounds run from C. The communicator is bootstrapped over the default process group;
+    before it is trusted it all-reduces a rank-dependent vector and checks the sums against a deadline.
+    -> the all-reduce callable, or None when any rank could not set it up (the caller then uses
+    torchAllReduce); every rank takes the same branch."""
+    import os
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    def allRanksOk(ok):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    ok = True
+    try:
+        eng.rcclLoad(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+    except Exception:
+        ok = False
+    if not allRanksOk(ok):
+        return None
+    ids = [None]
+    if rank == 0:
+        try:
+            ids[0] = eng.rcclUniqueId()
+        except Exception:
+            ids[0] = None
+    dist.broadcast_object_list(ids, src=0)
+    if ids[0] is None:
+        return None
+    ok = True
+    try:
+        eng.rcclInit(world, rank, ids[0])          # collective
+        eng.rcclSelfTest(timeoutSeconds)
+    except Exception:
+        ok = False
+    if not allRanksOk(ok):
+        try:
+            eng.rcclShutdown()
+        except Exception:
+            pass
+        return None
+
+    def allReduce():
+        eng.lmAllReduce()
+
+    allReduce.inLibrary = True
+    return allReduce
+
+
 def refineDistributed(modelName, P0, viewOffsets, sensorPoints, modelPoints, maxIters, dtype="f64",
                       checkEvery=8, engineFactory=None, allReduceFactory=None, **lmOptions):
     """Refine ONE global problem with the views sharded over the ranks of the default
@@ -111,7 +169,12 @@ def refineDistributed(modelName, P0, viewOffsets, sensorPoints, modelPoints, max
         local = int(os.environ.get("LOCAL_RANK", rank))
         eng = engine_mod.RefineEngine(modelName, dtype, local)
         eng.setProblem(ol, sl, ml)
-        allReduce = torchAllReduce(eng, torch.device("cuda", local))
+        allReduce = None
+        # CALIB_ALLREDUCE=direct|auto: the library issues ncclAllReduce itself (self-tested; torch otherwise)
+        if os.environ.get("CALIB_ALLREDUCE", "torch") != "torch" and dist.get_backend() == "nccl":
+            allReduce = directAllReduce(eng)
+        if allReduce is None:
+            allReduce = torchAllReduce(eng, torch.device("cuda", local))
     else:
         eng = engineFactory(ol, sl, ml)
         allReduce = allReduceFactory(eng)

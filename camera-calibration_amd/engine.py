@@ -195,6 +195,28 @@ class RefineEngine:
     def lmRun(self, rounds, checkEvery=0):
         nat.check(self._lib.calib_lm_run(self._h, int(rounds), int(checkEvery)))
 
+    # ---- in-library all-reduce (include/calib_lm.h: calib_rccl_*) -------------------------------
+    def rcclLoad(self, librcclPath):
+        nat.check(self._lib.calib_rccl_load(str(librcclPath).encode()))
+
+    def rcclUniqueId(self):
+        buf = ctypes.create_string_buffer(128)
+        nat.check(self._lib.calib_rccl_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
+        return bytes(buf.raw)
+
+    def rcclInit(self, nranks, rank, uniqueId):
+        buf = ctypes.create_string_buffer(bytes(uniqueId), 128)
+        nat.check(self._lib.calib_rccl_init(self._h, int(nranks), int(rank), ctypes.cast(buf, ctypes.c_void_p)))
+
+    def rcclSelfTest(self, timeoutSeconds=30.0):
+        nat.check(self._lib.calib_rccl_selftest(self._h, float(timeoutSeconds)))
+
+    def rcclShutdown(self):
+        nat.check(self._lib.calib_rccl_shutdown(self._h))
+
+    def lmAllReduce(self):
+        nat.check(self._lib.calib_lm_allreduce(self._h))
+
     def lmDone(self):
         d = ctypes.c_int(0)
         nat.check(self._lib.calib_lm_done(self._h, ctypes.byref(d)))

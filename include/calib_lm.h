@@ -129,6 +129,26 @@ int calib_lm_update(calib_handle_t h);
 /* rounds x (local, update) without a collective (single shard). If check_every > 0 the
  * host reads the device's done flag every check_every rounds and stops early. */
 int calib_lm_run(calib_handle_t h, int rounds, int check_every);
+
+/* ---- in-library all-reduce (optional) -------------------------------------------------------------
+ * The ONE exchange of the sharded loop can also be issued by the library itself, as ncclAllReduce on
+ * the engine's own stream (no hand-off to another framework's stream, and calib_lm_run then drives
+ * whole rounds -- local, all-reduce, update -- from C). RCCL is not linked: calib_rccl_load dlopens the
+ * librccl.so the process already uses (path given by the caller, e.g. the one PyTorch ships) and
+ * resolves ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy / ncclCommAbort.
+ *   rank 0: calib_rccl_unique_id(id) -> broadcast the 128 bytes by any means -> every rank:
+ *   calib_rccl_init(h, nranks, rank, id)   (collective)  -> calib_rccl_selftest(h, timeout_s)
+ * The self-test all-reduces a rank-dependent vector and checks the sums, polling the stream against the
+ * deadline; on a wrong answer or a timeout it aborts the communicator and returns CALIB_E_HIP, and the
+ * caller falls back to its own all-reduce (calib_lm_bind_reduce_buffer). After a successful
+ * calib_rccl_init, calib_lm_run all-reduces between calib_lm_local and calib_lm_update by itself;
+ * calib_lm_allreduce is that step alone, for callers that drive the three steps themselves. */
+int calib_rccl_load(const char* librccl_path);
+int calib_rccl_unique_id(void* out_id128);
+int calib_rccl_init(calib_handle_t h, int nranks, int rank, const void* id128);
+int calib_rccl_selftest(calib_handle_t h, double timeout_s);
+int calib_rccl_shutdown(calib_handle_t h);
+int calib_lm_allreduce(calib_handle_t h);
 int calib_lm_done(calib_handle_t h, int* out_done);           /* synchronises */
 /* Synchronise and copy trace row `iter` (CALIB_TRACE_HEADER + L doubles) of the running loop;
  * out_iters = LM iterations executed so far (rows >= that are not written yet). */

@@ -358,3 +358,40 @@ def test_c4_full_and_c5_shard_sizes_properties(tag, dtype, views, tolRecover):
     assert np.abs(Bsum - B).max() <= 1e-12 * np.abs(B).max()
     assert np.abs(parts[0][3][:L] + parts[1][3][:L] - g[:L]).max() <= 1e-10 * max(np.abs(g[:L]).max(), 1e-300) + 1e-6
     assert np.array_equal(np.concatenate((parts[0][2], parts[1][2])), V)      # per-view blocks are shard-local
+
+
+def test_in_library_allreduce_world_size_1(c3):
+    """The optional in-library exchange (calib_rccl_*: RCCL dlopened from the library PyTorch ships,
+    communicator bootstrapped over the process group, self-test, whole rounds driven from C) at world size
+    1 gives bitwise the result of the torch.distributed path."""
+    import torch
+    import torch.distributed as dist
+    L, nv = 9, 300
+    offs = c3["viewOffsets"][:nv + 1]
+    n = int(offs[-1])
+    s, m = c3["sensorPoints"][:n], c3["modelPoints"][:n]
+    P0 = np.concatenate((c3["P0"][:L], c3["P0"][L:L + 6 * nv]))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        outs = []
+        for direct in (False, True):
+            eng = cca.RefineEngine("fisheye", "f64")
+            eng.setProblem(offs, s, m)
+            ar = distributed.directAllReduce(eng, timeoutSeconds=20.0) if direct \
+                else distributed.torchAllReduce(eng, torch.device("cuda", 0))
+            assert ar is not None and bool(getattr(ar, "inLibrary", False)) == direct
+            lm = distributed.ShardedLM(eng, ar)
+            lm.begin(P0, 40)
+            lm.run(40, checkEvery=8)
+            outs.append(lm.end())
+            if direct:
+                eng.rcclShutdown()
+            eng.close()
+        assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+        assert outs[1][0] < 1e-9 * n
+    finally:
+        dist.destroy_process_group()
