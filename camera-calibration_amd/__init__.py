@@ -9,7 +9,7 @@ from . import (_native, calibrate, dataset, distortion, engine, jacobian, linear
 from .calibrate import Calibrator, getSensorPoints  # noqa: F401
 from .distortion import FisheyeModel, RadialTangentialModel  # noqa: F401
 from .engine import RefineEngine  # noqa: F401
-from .jacobian import ProjectionJacobian, createJacRadTan  # noqa: F401
+from .jacobian import HomographyJacobian, ProjectionJacobian, createJacRadTan  # noqa: F401
 from .main import calibrateCamera  # noqa: F401
 
 __version__ = "0.1.0"

@@ -55,6 +55,7 @@ SIGNATURES = {
                                                      _c_double_p, _c_double_p]),
     "calib_refine_homographies": (ctypes.c_int, [ctypes.c_int64, _c_int64_p, _c_double_p, _c_double_p, _c_double_p,
                                                  ctypes.c_int, ctypes.c_int]),
+    "calib_homography_jacobian": (ctypes.c_int, [ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p, ctypes.c_int]),
     "calib_estimate_homographies": (ctypes.c_int, [ctypes.c_int64, _c_int64_p, _c_double_p, _c_double_p, _c_double_p,
                                                    ctypes.c_int, ctypes.c_int]),
     "calib_compute_extrinsics": (ctypes.c_int, [ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p, ctypes.c_int]),

@@ -50,6 +50,20 @@ class Calibrator:
         offs, sensor, model = engine.packDetections(allDetections)
         return list(engine.refineHomographies(Hs, offs, sensor, model, 20, self._device))
 
+    def _refineHomography(self, H, sensorPoints, modelPoints, jac=None):
+        """LM polish of ONE homography (src/calibrate.py:69-111): the same 20-iteration loop, on the
+        device; `jac` (a HomographyJacobian in the reference) is accepted and not needed."""
+        s = np.asarray(sensorPoints, dtype=np.float64).reshape(-1, 2)
+        m = np.asarray(modelPoints, dtype=np.float64).reshape(-1, 3)
+        offs = np.array([0, s.shape[0]], dtype=np.int64)
+        return engine.refineHomographies(np.asarray(H, dtype=np.float64).reshape(1, 3, 3), offs, s, m, 20,
+                                         self._device)[0]
+
+    def _projectPointsHomography(self, H, modelPoints):
+        """src/calibrate.py:113-115"""
+        modelPoints = np.asarray(modelPoints, dtype=np.float64)
+        return mu.unhom((np.asarray(H, dtype=np.float64) @ mu.hom(modelPoints[:, :2]).T).T)
+
     # ---- the hot path --------------------------------------------------------------------
     def refineCalibrationParameters(self, Ainitial, Winitial, kInitial, allDetections,
                                     maxIters, shouldPrint=False):

@@ -38,10 +38,15 @@ int fail(int code, const std::string& msg) {
     if (!(h)) return fail(CALIB_E_INVALID, "null handle");                                    \
     HIP_TRY(hipSetDevice((h)->device))
 
+// Device allocation owned by its scope: every early return of an entry point (HIP_TRY) releases it.
 template <typename U>
 struct DevBuf {
     U* p = nullptr;
     size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
     hipError_t alloc(size_t count) {
         if (count <= n && p) return hipSuccess;
         release();
@@ -86,6 +91,7 @@ struct calib_handle_s {
     DevBuf<int> pt_view, view_ext, item_n, view_item0, item_view;
     DevBuf<uint32_t> emit_tab;    // fused kernel's record assembly table (buildEmitTable)
     int lm_mode = CALIB_LM_FUSED;
+    int num_cus = 256;
     DevBuf<int64_t> item_pt0;
     DevBuf<double> sse_part, G[2], bpart, part, red_own, P[2], Peval, trace;
     int n_bpart = 0;              // workgroup partials of the shared block written by this round's pass
@@ -365,6 +371,11 @@ int calib_create(int model, int dtype, int device_id, calib_handle_t* out_handle
         }
     }
     if (const char* e = std::getenv("CALIB_LM_MODE")) h->lm_mode = std::atoi(e) ? CALIB_LM_TWO_KERNEL : CALIB_LM_FUSED;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0)
+            h->num_cus = cus;
+    }
     *out_handle = h;
     return CALIB_OK;
 }
@@ -1051,6 +1062,23 @@ int calib_estimate_homographies(int64_t num_views, const int64_t* view_offsets, 
             if (view_offsets[i + 1] - view_offsets[i] < 4)
                 return fail(CALIB_E_INVALID, "a homography needs at least 4 point correspondences per view");
     return homography_pipeline(num_views, view_offsets, sensor_uv, model_xyz, H_out, true, refine_iters, device_id);
+}
+
+int calib_homography_jacobian(int64_t n, const double* h9, const double* model_xyz, double* out_J, int device_id) {
+    if (n < 0 || !h9 || (n > 0 && (!model_xyz || !out_J))) return fail(CALIB_E_INVALID, "null argument");
+    if (n == 0) return CALIB_OK;
+    int rc = use_device(device_id);
+    if (rc) return rc;
+    DevBuf<double> dh, dx, dJ;
+    HIP_TRY(dh.alloc(9));
+    HIP_TRY(dx.alloc((size_t)n * 3));
+    HIP_TRY(dJ.alloc((size_t)n * 18));
+    HIP_TRY(hipMemcpy(dh.p, h9, 72, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dx.p, model_xyz, (size_t)n * 24, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(homography_jacobian_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dh.p, dx.p, n, dJ.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out_J, dJ.p, (size_t)n * 18 * 8, hipMemcpyDeviceToHost));
+    return CALIB_OK;
 }
 
 int calib_compute_extrinsics(int64_t num_views, const double* A, const double* H, double* W_out, int device_id) {

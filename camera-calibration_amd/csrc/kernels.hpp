@@ -339,6 +339,10 @@ __global__ __launch_bounds__(256) void gram_kernel(const typename Pair<T>::type*
 // odd number of 16-B chunks: conflict-free ds_write_b128 / ds_read_b128) into the MFMA operand
 // map (lane (k, c) <- point 4s+k, column c) and feeds v_mfma_f64_16x16x4_f64. The view constants
 // are wave-uniform (scalar loads). HBM traffic per point: the 40 B of inputs (5 values of width w).
+// On a gfx950 SIMD, v_mfma_f64 and VALU instructions of DIFFERENT waves do not overlap either (tools/ubench:
+// FMA-only waves make no progress while a SIMD mate streams fp64 MFMAs), so the kernel's floor is the sum of
+// its matrix and vector issue time; a producer / consumer split of the waves and a persistent-wave form were
+// both built and measured slower.
 constexpr int kFusedRowChunks = 17;                       // 16 columns + 1 pad chunk (odd => conflict-free)
 
 // ROWS = points transposed per LDS pass (32: two passes per 64-point batch, half the lanes
@@ -396,6 +400,10 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
             c4.x = T(0); c4.y = T(1);
             slab[lane * RS + 3] = c3;
             if (!ONES) slab[lane * RS + 4] = c4;
+            // columns 0, 1, 2 are (xd, 0), (0, yd), (yd, 0): their zero halves are set once, the batches
+            // store only the other 8 bytes
+            T* zr = reinterpret_cast<T*>(slab + lane * RS);
+            zr[1] = T(0); zr[2] = T(0); zr[5] = T(0);
         }
         // inputs of the next batch are requested before the current batch is evaluated
         int64_t pn = pbeg + (qbeg + lane < qend ? qbeg + lane : qend - 1);
@@ -423,9 +431,10 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
                 __builtin_amdgcn_wave_barrier();
                 if (HALVES == 1 || (lane >> 5) == half) {
                     T2* row = slab + (lane & (ROWS - 1)) * RS;
+                    T* rh = reinterpret_cast<T*>(row);
+                    rh[0] = Jc[0].x; rh[3] = Jc[1].y; rh[4] = Jc[2].x;  // the non-zero halves of columns 0, 1, 2
 #pragma unroll
-                    for (int cc = 0; cc < C; ++cc)
-                        if (cc != 3 && cc != 4) row[cc] = Jc[cc];       // columns 3, 4 are constants, set once above
+                    for (int cc = 5; cc < C; ++cc) row[cc] = Jc[cc];    // columns 3, 4 are constants, set once above
                     if (RCOL) row[15] = res;                    // spare 16th column carries the residual
                     if (ONES) row[4] = res;
                 }
@@ -1188,6 +1197,25 @@ __global__ __launch_bounds__(256) void homography_lm_kernel(const int64_t* __res
     }
 #pragma unroll
     for (int j = 0; j < 9; ++j) if (i == j) H[view * 9 + j] = h[j] / h[8];       // Href /= Href[2,2]
+}
+
+// HomographyJacobian.compute (src/jacobian.py:88-121): rows (du, dv)/dh of the projection of (X, Y, 1)
+// through H = h.reshape(3,3), interleaved per point; one thread per point, out (2N, 9) row-major.
+__global__ void homography_jacobian_kernel(const double* __restrict__ h, const double* __restrict__ xyz, int64_t n,
+                                           double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double X = xyz[3 * i], Y = xyz[3 * i + 1];
+    const double iw = 1.0 / (h[6] * X + h[7] * Y + h[8]);
+    const double u = (h[0] * X + h[1] * Y + h[2]) * iw, v = (h[3] * X + h[4] * Y + h[5]) * iw;
+    const double p[3] = {X * iw, Y * iw, iw};
+    double* ru = out + 18 * i;
+    double* rv = ru + 9;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        ru[j] = p[j];       ru[3 + j] = 0.0;   ru[6 + j] = -u * p[j];
+        rv[j] = 0.0;        rv[3 + j] = p[j];  rv[6 + j] = -v * p[j];
+    }
 }
 
 // ---------------------------------------------------------------- closed-form initialisation (per view)

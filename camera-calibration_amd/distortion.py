@@ -38,6 +38,16 @@ class DistortionModel:
             raise ValueError(f"Expected shape (None, 2), got {x.shape}")
         return engine.distortPoints(self.modelId, x, self._checkK(k))
 
+    def estimateDistortion(self, A, allDetections, allBoardPosesInCamera, device=0):
+        """Linear least-squares start value of k given A and the board poses (src/distortion.py:70,
+        110-191 radial-tangential, 222-271 fisheye): D^T D and D^T Ddot are formed on the device
+        (calib_distortion_normal_equations), the |k| x |k| system is solved on the host."""
+        from . import linearcalibrate
+        offs, sensor, model = engine.packDetections(allDetections)
+        DtD, Dtd = engine.distortionNormalEquations(self.modelId, offs, sensor, model, A,
+                                                    np.asarray(allBoardPosesInCamera, dtype=np.float64), device)
+        return linearcalibrate.solveDistortionNormalEquations(DtD, Dtd)
+
     def _checkK(self, k):
         k = np.asarray(k, dtype=np.float64).ravel()
         n = len(self.getDistortionSymbols())

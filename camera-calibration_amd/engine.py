@@ -266,6 +266,20 @@ def refineHomographies(Hs, viewOffsets, sensorPoints, modelPoints, maxIters=20, 
     return H
 
 
+def homographyJacobian(h, modelPoints, device=0):
+    """(2N, 9) Jacobian of the homography projection wrt h (src/jacobian.py:88-121), on the device."""
+    h = np.ascontiguousarray(np.asarray(h, dtype=np.float64).ravel())
+    m = np.ascontiguousarray(modelPoints, dtype=np.float64)
+    if h.shape[0] != 9:
+        raise ValueError(f"Expected shape (9,), got {h.shape}")
+    if m.ndim != 2 or m.shape[1] != 3:
+        raise ValueError(f"Expected shape (None, 3), got {m.shape}")
+    J = np.empty((2 * m.shape[0], 9))
+    nat.requireDevice()
+    nat.check(nat.loadLibrary().calib_homography_jacobian(m.shape[0], nat.dptr(h), nat.dptr(m), nat.dptr(J), int(device)))
+    return J
+
+
 def _packedViews(viewOffsets, sensorPoints, modelPoints):
     offs = np.ascontiguousarray(viewOffsets, dtype=np.int64)
     s = np.ascontiguousarray(sensorPoints, dtype=np.float64).reshape(-1, 2)

@@ -76,6 +76,18 @@ class ProjectionJacobian:
         return self._blocks(intrinsicValues, extrinsicValues, modelPoints)[:, L:].copy()
 
 
+class HomographyJacobian:
+    """Drop-in for src/jacobian.py:88-121: same constructor and compute(h, modelPoints); the nine
+    closed-form columns come from a device kernel instead of a lambdified sympy expression."""
+
+    def __init__(self, device=0):
+        self._device = device
+
+    def compute(self, h, modelPoints):
+        """h = (H11 .. H33), modelPoints (N,3) -> J (2N, 9), rows (u_j, v_j) interleaved."""
+        return engine.homographyJacobian(h, np.asarray(modelPoints, dtype=np.float64), self._device)
+
+
 def createJacRadTan() -> ProjectionJacobian:
     """src/jacobian.py:189-192"""
     return ProjectionJacobian(distortion.RadialTangentialModel())

@@ -122,3 +122,75 @@ def transform(b_M_a, aX):
     validateShape(b_M_a.shape, (4, 4))
     validateShape(aX.shape, (None, 3))
     return aX @ b_M_a[:3, :3].T + b_M_a[:3, 3]
+
+
+def radians(angleDegrees):
+    """src/mathutils.py:9-10"""
+    return angleDegrees / 180.0 * np.pi
+
+
+def skew(v):
+    """'hat' operator: (3,1) vector -> skew-symmetric (3,3) (src/mathutils.py:84-94)"""
+    v = np.asarray(v)
+    validateShape(v.shape, (3, 1))
+    x, y, z = v[:, 0]
+    return np.array([[0, -z, y], [z, 0, -x], [-y, x, 0]])
+
+
+def unskew(vHat):
+    """inverse of skew: (3,3) -> (3,) (src/mathutils.py:97-99)"""
+    vHat = np.asarray(vHat)
+    validateShape(vHat.shape, (3, 3))
+    return np.array([vHat[2, 1], vHat[0, 2], vHat[1, 0]])
+
+
+def exp(wHat):
+    """so(3) -> SO(3), Rodrigues' formula with the reference's numeric guard: an angle with
+    np.isclose(|w|, 0) maps to the identity (src/mathutils.py:59-81). The reference's
+    isSymbolic=True branch builds sympy expressions for its lambdified Jacobian; the closed-form
+    device Jacobian replaces it (csrc/point_model.hpp), so only the numeric mapping exists here."""
+    wHat = np.asarray(wHat, dtype=np.float64)
+    w = unskew(wHat)
+    n = np.linalg.norm(w)
+    if np.isclose(n, 0):
+        return np.eye(3)
+    K = wHat / n
+    return np.eye(3) + np.sin(n) * K + (1.0 - np.cos(n)) * (K @ K)
+
+
+def stack(A):
+    """columns of a matrix stacked into one column (src/mathutils.py:108-110)"""
+    return col(np.asarray(A).T.ravel())
+
+
+def unstack(As):
+    """inverse of stack for a square matrix (src/mathutils.py:113-117)"""
+    As = np.asarray(As)
+    N = int(np.sqrt(As.size))
+    return As.reshape((N, N)).T
+
+
+def normalize(A):
+    """scale so that the last element is 1 (src/mathutils.py:137-138)"""
+    A = np.asarray(A)
+    return A / A.ravel()[-1]
+
+
+def projectStandard(X):
+    """(N,3) camera-frame points -> (N,2) normalised image points (src/mathutils.py:174-192)"""
+    X = np.asarray(X, dtype=np.float64)
+    validateShape(X.shape, (None, 3))
+    return X[:, :2] / X[:, 2:3]
+
+
+def project(A, wMc, wX):
+    """pinhole projection of world points: A (3,3), camera pose in world wMc (4,4), wX (N,3)
+    -> (N,2) pixels (src/mathutils.py:149-171)"""
+    A = np.asarray(A, dtype=np.float64)
+    wMc = np.asarray(wMc, dtype=np.float64)
+    wX = np.asarray(wX, dtype=np.float64)
+    validateShape(A.shape, (3, 3))
+    validateShape(wMc.shape, (4, 4))
+    validateShape(wX.shape, (None, 3))
+    x = projectStandard(transform(np.linalg.inv(wMc), wX))
+    return unhom(hom(x) @ A.T)

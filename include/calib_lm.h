@@ -173,6 +173,12 @@ int calib_project_with_distortion(int model, int64_t n, const double* A, const d
 int calib_refine_homographies(int64_t num_views, const int64_t* view_offsets, const double* sensor_uv,
                               const double* model_xyz, double* H_inout, int max_iters, int device_id);
 
+/* HomographyJacobian.compute (src/jacobian.py:88-121): the (2N, 9) Jacobian of the projection of the
+ * model points (X, Y, 1) through H = h.reshape(3,3) with respect to h, rows (u_j, v_j) interleaved.
+ * h9 (9), model_xyz (N,3): only X, Y are used; out_J (2N,9) row-major. */
+int calib_homography_jacobian(int64_t n, const double* h9, const double* model_xyz, double* out_J,
+                              int device_id);
+
 /* ---- closed-form initialisation stage on the device (Calibrator.estimateCalibrationParameters,
  * src/calibrate.py:41-58). The 6-unknown intrinsics fit and the <= 5-unknown distortion solve stay on
  * the host; everything that is per view / per point runs here. ------------------------------------

@@ -32,3 +32,4 @@ f, fn = eng.profileRead(2)
 MN = int(sh["viewOffsets"][-1])
 print(f"{a.workload} MN={MN} ms/iter {el/a.steps*1e3:.4f}  jac {j/max(jn,1)*1e3:.1f} us  gram {g/max(gn,1)*1e3:.1f} us  "
       f"fused {f/max(fn,1)*1e3:.1f} us  launches {jn} {gn} {fn}")
+eng.close()

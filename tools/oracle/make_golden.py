@@ -15,9 +15,10 @@ G2  config 1 (10 views x 54 pts, 9x6 board) radtan + fisheye: detections, poses,
     and the final (sse, A, W, k)       (src/calibrate.py:117-171)
 G3  the 15-view 25x18 unit-test dataset (ragged views) of tests/test_calibrate.py:41-45
 G4  tests/itest_main.py:12-29 realistic radtan calibration (final A, k)
-G5  200 ragged views x <=54 pts: P0, dense delta, Schur inputs
+G5  200 ragged views x <=54 pts: P0, dense delta, Schur inputs (g5k: the same at 1000 views, config 2's scale)
 G6  synthetic-generator poses for the bench boards (src/dataset.py:59-95)
 G7  DLT homographies and their LM polish (src/linearcalibrate.py:7-58, src/calibrate.py:60-115)
+G8  HomographyJacobian.compute and the mathutils helpers exp/skew/unskew/stack/unstack/project/projectStandard
 """
 import argparse
 import os
@@ -192,13 +193,12 @@ def g4():
     save("g4_realistic.npz", **_fullProblem(cal, ds, 100, "g4", False))
 
 
-def g5():
+def g5(M=200):
     A = np.array([[400, 0, 320], [0, 400, 240], [0, 0, 1]], dtype=np.float64)
     k = (-0.5, 0.2, 0.07, -0.03, 0.05)
     cal = ref.getCalibrator("radtan")
     cam = ref.virtualcamera.VirtualCamera(A, k, ref.distortion.RadialTangentialModel(),
                                           640, 480, None)
-    M = 200
     ds = ref.dataset.Dataset(ref.checkerboard.Checkerboard(9, 6, 0.05), cam, M)
     allDetections = ds.getCornerDetectionsInSensorCoordinates()
     keep = [d for d in allDetections if d[0].shape[0] >= 6]
@@ -225,11 +225,16 @@ def g5():
     err0 = cal._computeReprojectionError(P0, allDetections)
     err1 = cal._computeReprojectionError(P0 + delta, allDetections)
     L = 10
-    save("g5_ragged200.npz", viewOffsets=offs, sensorPoints=sensor, modelPoints=model,
+    save(f"g5_ragged{M}.npz", viewOffsets=offs, sensorPoints=sensor, modelPoints=model,
          Ptrue=Ptrue, P0=P0, y0=y0, JTr=JTr, delta=delta,
          B=JTJ[:L, :L], diagJTJ=np.diagonal(JTJ).copy(),
          err0=np.float64(err0), err1=np.float64(err1),
          Jview0=J[:2 * (offs[1] - offs[0]), :], lam=np.float64(lam))
+
+
+def g5k():
+    """G5 at config 2's scale: 1000 ragged views (one dense reference step, ~10 min and ~12 GB here)."""
+    g5(1000)
 
 
 def g6():
@@ -283,6 +288,40 @@ def g7():
         out.update({f"{tag}_viewOffsets": offs, f"{tag}_sensorPoints": sensor, f"{tag}_modelPoints": model,
                     f"{tag}_H": Hdlt, f"{tag}_Href": np.array(Hsref)})
     save("g7_homographies.npz", **out)
+
+
+def g8():
+    """Surface helpers: HomographyJacobian.compute (src/jacobian.py:88-121, incl. the call shape of
+    tests/test_jacobian.py:79-89) and the mathutils functions exp / skew / unskew / stack / unstack /
+    project / projectStandard (src/mathutils.py:59-117,149-192; call shapes of tests/test_mathutils.py)."""
+    out = {}
+    hj = ref.jacobian.HomographyJacobian()
+    g7 = np.load(os.path.join(OUT, "g7_homographies.npz"))
+    board = ref.checkerboard.Checkerboard(9, 6, 0.05).getCornerPositions()
+    Hs = [np.eye(3), g7["c1_Href"][0], g7["c1_Href"][3], np.array([[1.1, 0.2, 3.0], [-0.3, 0.9, 1.0], [0.01, -0.02, 1.3]])]
+    pts = [np.arange(15, dtype=np.float64).reshape(-1, 3), board, board, board + 0.013]
+    for i, (H, mp) in enumerate(zip(Hs, pts)):
+        out[f"hj{i}_h"] = H.ravel().astype(np.float64)
+        out[f"hj{i}_modelPoints"] = mp
+        out[f"hj{i}_J"] = np.asarray(hj.compute(H.ravel(), mp), dtype=np.float64)
+    rng = np.random.default_rng(5)
+    ws = np.vstack([rng.uniform(-3, 3, (12, 3)), [[0, 0, 0], [1e-9, 0, 0], [0, 0, np.pi], [np.pi / 2, 0, 0]]])
+    mu = ref.mathutils
+    out["exp_w"] = ws
+    out["exp_R"] = np.array([mu.exp(mu.skew(mu.col(w))) for w in ws], dtype=np.float64)
+    out["skew"] = np.array([mu.skew(mu.col(w)) for w in ws], dtype=np.float64)
+    out["unskew"] = np.array([mu.unskew(mu.skew(mu.col(w))) for w in ws], dtype=np.float64)
+    Amat = np.arange(9, dtype=np.float64).reshape(3, 3) + 0.5
+    out["stack_A"], out["stack_out"] = Amat, mu.stack(Amat)
+    out["unstack_out"] = mu.unstack(mu.stack(Amat))
+    A = np.array([[400, 0.5, 320], [0, 410, 240], [0, 0, 1]], dtype=np.float64)
+    wMc = mu.poseFromRT(mu.eulerToRotationMatrix((170, 12, -33)), (0.1, -0.2, 0.9))
+    wX = rng.uniform(-0.3, 0.3, (20, 3))
+    out["project_A"], out["project_wMc"], out["project_wX"] = A, wMc, wX
+    out["project_u"] = mu.project(A, wMc, wX)
+    Xc = rng.uniform(-1, 1, (20, 3)) + np.array([0, 0, 2.5])
+    out["projectStandard_X"], out["projectStandard_x"] = Xc, mu.projectStandard(Xc)
+    save("g8_surface.npz", **out)
 
 
 if __name__ == "__main__":
