@@ -28,9 +28,24 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MATRIX_PEAK_TFLOPS = 78.6  # public MI355X sheet; fp64 MFMA = fp64 vector rate
-# fp64 VALU flops the fused kernel executes per 64-point wave batch (all 64 lanes counted), from
-# rocprofv3 --pmc SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 (profiles/README.md): 64 x (2 FMA + MUL + ADD + TRANS)
-FUSED_VALU_F64_FLOPS_PER_BATCH = {"fisheye": 17.3e3, "radtan": 11.9e3}
+# fp64 VALU flops the fused kernel executes per 64-point wave batch (all 64 lanes counted) and its HBM traffic
+# are MEASURED quantities of a particular build: rocprofv3 --pmc passes (tools/pmc_pass.sh) summarised into
+# profiles/pmc_fused.json by tools/pmc_summary.py together with the commit they were taken at. bench.py quotes
+# them with that source; it does not re-measure counters (gpurun forbids mixing --pmc with the timed run).
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_fused.json")
+
+
+def measuredCounters(workload, model):
+    """-> (valu fp64 flops per 64-lane batch or None, fused kernel HBM bytes per launch or None,
+    jacobian kernel HBM bytes per launch or None, source string)"""
+    try:
+        d = json.load(open(PMC_FILE))
+    except Exception:
+        return None, None, None, None
+    e = d.get(workload) or {}
+    flops = e.get("valu_f64_flops_per_batch") or (d.get("by_model", {}).get(model) or {}).get("valu_f64_flops_per_batch")
+    src = e.get("source") or (d.get("by_model", {}).get(model) or {}).get("source")
+    return flops, e.get("fused_hbm_bytes_per_launch"), e.get("jacobian_hbm_bytes_per_launch"), src
 
 
 def algorithmicBytesPerPoint(L, wordBytes):
@@ -104,7 +119,9 @@ def cpuBaseline(shard, cfgName, seconds=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=100, help="LM iterations per timed segment (<= 100)")
+    ap.add_argument("--min-seconds", type=float, default=0.5,
+                    help="the K-step segment is repeated until the timed phase lasts at least this long")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", help="c2 | c3 | c4 | c5 (BASELINE.json configs[1..4])")
     ap.add_argument("--views", type=int, default=None, help="views per GPU (default: the config's)")
@@ -176,12 +193,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()      # the engine's own stream was synchronised by the segment's lmEnd
 
-    # The LM loop runs in segments of at most SEG iterations; every segment is a fresh refinement of
-    # the same perturbed start point (lambda back at 1e-3, src/calibrate.py:142): with the stop rule
-    # disabled, lambda would otherwise overflow after ~310 consecutive rejections at the noise floor.
-    # A segment's bootstrap pass (one extra evaluation of all points) is inside the timed region but
-    # not counted as a step.
+    # A timed SEGMENT is exactly K = --steps LM iterations of one refinement: lmBegin (upload of P0, state reset)
+    # and the bootstrap pass that evaluates P0 are issued and drained BEFORE the clock starts, lmEnd (download of
+    # P and the trace) runs after it stops -- they are per-refinement costs, reported as segment_overhead_ms.
+    # With the stop rule disabled lambda overflows after ~310 consecutive rejections at the noise floor, so a
+    # segment holds at most SEG iterations and every segment restarts from the same perturbed P0 (lambda 1e-3,
+    # src/calibrate.py:142). The segment is repeated R times (R agreed by all ranks from one calibration
+    # segment, so that the timed phase lasts >= 0.5 s) and the MEDIAN segment is reported: a 100-iteration c3
+    # segment is 8 ms, too short for the clocks and for a sampling profiler to see.
     SEG = 100
+    if args.steps > SEG:
+        sys.exit(f"bench.py: --steps is at most {SEG} (lambda leaves the fp64 range in longer runs with the stop rule off)")
     allReduceKind = None
     if dist is not None:
         allReduce = None
@@ -196,51 +218,78 @@ def main():
         lm = distributed.ShardedLM(eng, allReduce)
     state = {"P": shard["P0"], "iters": 0, "trace": [], "sse": float("nan")}
 
-    def runSteps(n):
-        done = 0
-        while done < n:
-            k = min(SEG, n - done)
-            # every segment is begun with the same iteration capacity (the trace buffer is sized by it:
-            # a warm-up begun smaller would leave a device reallocation inside the timed region) and
-            # run for exactly k iterations after the bootstrap pass
-            if dist is not None:
-                lm.begin(shard["P0"], SEG, **lmOpts)
-                lm.run(k)
-            else:
-                eng.lmBegin(shard["P0"], SEG, **lmOpts)
-                eng.lmRun(k + 1)
-            done += k
-            sse_, P_, it_, tr_ = eng.lmEnd()          # synchronises
-            state["P"], state["sse"] = P_, sse_
-            state["iters"] += it_
-            state["trace"].append(tr_)
+    def drain():
+        eng.lmDone()                  # synchronises the engine's stream (reads the done flag)
+        torch.cuda.synchronize()
+
+    def segment(k, timed=True):
+        """one refinement of k iterations -> (seconds for the k iterations, seconds of begin + bootstrap + end)"""
+        tb = time.perf_counter()
+        # every segment is begun with the same iteration capacity (the trace buffer is sized by it)
+        if dist is not None:
+            lm.begin(shard["P0"], SEG, **lmOpts)          # lmBegin + bootstrap round
+        else:
+            eng.lmBegin(shard["P0"], SEG, **lmOpts)
+            eng.lmRun(1)
+        drain()
+        if timed:
+            barrier()
+        t0 = time.perf_counter()
+        if dist is not None:
+            lm.run(k)
+        else:
+            eng.lmRun(k)
+        drain()
+        if timed:
+            barrier()
+        t1 = time.perf_counter()
+        sse_, P_, it_, tr_ = eng.lmEnd()
+        t2 = time.perf_counter()
+        state["P"], state["sse"] = P_, sse_
+        state["iters"] += it_
+        state["trace"].append(tr_)
+        return t1 - t0, (t0 - tb) + (t2 - t1)
 
     # Everything slow is done before the warm-up, so that the device is not left idle between the warm-up
     # and the timed region: after >= 20 ms of idleness the GPU's clocks have dropped and the next ~1 ms of
-    # work runs slow (measured: a 100-iteration segment takes 8.4 ms back to back, 9.2 ms after a pause --
-    # 9 % of a 100-step timed region). So: event pool and collector first, then an untimed spin-up that
-    # brings the clocks up (setup, like generating the data), the W warm-up steps, barrier, clock.
+    # work runs slow. So: event pool and collector first, then an untimed spin-up that brings the clocks up
+    # (setup, like generating the data), the W warm-up steps, then the timed segments back to back.
     import gc
     # HIP events around the dominant kernel's launches inside the timed region, on the stream they are
     # launched on. An event pair keeps a launch from being dispatched back to back with its neighbours
-    # (c3: +12 us per LM round when every launch is bracketed), so every PROF_EVERY-th launch is timed (>= 6 samples).
+    # (c3: +12 us per LM round when every launch is bracketed), so every PROF_EVERY-th launch is timed.
     PROF_EVERY = max(1, min(16, args.steps // 6)) if args.lm_mode == "fused" else 1
     eng.profileEnable(True, every=PROF_EVERY)             # creates the event pool (tens of ms, once)
     gc.collect()
     gc.disable()              # no collector pauses inside the timed region (ranks wait for the slowest each round)
     tSpin = time.perf_counter()
-    runSteps(3 * SEG)                                      # clock spin-up, ~25 ms of device work
+    for _ in range(3):
+        segment(SEG, timed=False)                          # clock spin-up, ~25 ms of device work
     tSpin = time.perf_counter() - tSpin
-    runSteps(args.warmup)
-    barrier()
+    if args.warmup > 0:
+        segment(min(args.warmup, SEG), timed=False)
+    # one calibration segment fixes the repeat count on every rank
+    tCal, _ = segment(args.steps)
+    if dist is not None:
+        tc = torch.tensor([tCal], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+        tCal = float(tc.item())
+    R = int(min(301, max(5, np.ceil(args.min_seconds / max(tCal, 1e-6)))))
+    R += 1 - R % 2                                         # odd: the median is one of the segments
     itersBefore = state["iters"]
     state["trace"] = []
     eng.profileEnable(True, every=PROF_EVERY)             # counters back to zero (cheap: the pool exists)
-    t0 = time.perf_counter()
-    runSteps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    segTimes, segOver = np.zeros(R), np.zeros(R)
+    tPhase = time.perf_counter()
+    for j in range(R):
+        segTimes[j], segOver[j] = segment(args.steps)
+    tPhase = time.perf_counter() - tPhase
     gc.enable()
+    if dist is not None:                                   # per segment: the slowest rank
+        tt = torch.from_numpy(segTimes.copy()).to("cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        segTimes = tt.cpu().numpy()
+    elapsed = float(np.median(segTimes))
     jacMs, jacN = eng.profileRead(0)
     gramMs, gramN = eng.profileRead(1)
     fusedMs, fusedN = eng.profileRead(2)
@@ -248,7 +297,7 @@ def main():
     sse, P = state["sse"], state["P"]
     iters = state["iters"] - itersBefore
     trace = np.vstack(state["trace"]) if state["trace"] else np.zeros((0, 5 + eng.L))
-    total = args.steps
+    total = args.steps * R
     twoKernelMsPerStep = None
     jacSteps = gramSteps = args.steps
     if rank == 0 and args.lm_mode == "fused":
@@ -276,9 +325,6 @@ def main():
             print(f"bench: two-kernel pass skipped: {e}", file=sys.stderr)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         n = torch.tensor([MNlocal], dtype=torch.int64, device="cuda")
         dist.all_reduce(n)
         MNglobal = int(n.item())
@@ -299,17 +345,11 @@ def main():
         C = L + 6
         gramFlops = (4 * 16 * 16 + 4 * C) * gramPts      # as executed on full 16x16 MFMA tiles + J^T r
         accepted = int(trace[:, 4].sum())
-        pmc = {}
-        trafficFile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(trafficFile):
-            try:
-                pmc = json.load(open(trafficFile)).get(args.workload, {})
-            except Exception:
-                pmc = {}
-        traffic = pmc.get("jacobian_bytes_per_launch")
+        valuPerBatch, fusedTraffic, jacTraffic, pmcSource = measuredCounters(args.workload, cfg["model"])
         jacRoof = {"kernel": "jacobian_kernel (two-kernel mode)", "bound": "hbm",
                    "achieved": jacGBs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": (jacGBs / HBM_PEAK_GBS) if jacGBs else None, "traffic": traffic,
+                   "frac": (jacGBs / HBM_PEAK_GBS) if jacGBs else None, "traffic": jacTraffic,
+                   "traffic_source": pmcSource if jacTraffic else None,
                    "algorithmic_bytes_per_launch": jacBytes * jacPts, "points_per_launch": jacPts,
                    "launches_per_step": jacN / jacSteps,
                    "avg_launch_ms": jacAvgMs, "launches_timed": jacN}
@@ -317,15 +357,22 @@ def main():
             fusedAvgMs = fusedMs / fusedN
             fusedPts = MNlocal
             mfmaFlops = 4 * 16 * 16 * fusedPts               # 2 x v_mfma_f64_16x16x4 (2048 flop) per 4 points
-            # fp64 MFMA and fp64 VALU never co-execute on gfx950 (SQ_VALU_MFMA_COEXEC_CYCLES = 0, and
-            # matrix peak = vector peak): both draw on the one 78.6 TFLOP/s fp64 budget
+            # An fp64 MFMA blocks the VALU of every wave on its SIMD (tools/ubench; SQ_VALU_MFMA_COEXEC_CYCLES = 0)
+            # and matrix peak = vector peak: both kinds of fp64 work draw on the one 78.6 TFLOP/s budget.
+            # `achieved` counts the VALU flops of every lane of every 64-lane batch the kernel executes;
+            # `useful_frac` counts a view's last, partly filled batch only for its live lanes.
             batches = viewsPerGpu * (-(-shard["pointsPerView"] // 64))
-            valuFlops = (FUSED_VALU_F64_FLOPS_PER_BATCH[cfg["model"]] * batches) if cfg["dtype"] == "f64" else 0.0
+            f64 = cfg["dtype"] == "f64"
+            valuFlops = valuPerBatch * batches if (valuPerBatch and f64) else 0.0
+            valuUseful = valuPerBatch * fusedPts / 64.0 if (valuPerBatch and f64) else 0.0
             tf = (mfmaFlops + valuFlops) / (fusedAvgMs * 1e-3) / 1e12
             mainRoof = {"kernel": "fused_kernel (jacobian blocks + v_mfma_f64_16x16x4_f64 J^T J, J on-chip)",
                         "bound": "mfma", "achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": tf / FP64_MATRIX_PEAK_TFLOPS, "traffic": pmc.get("fused_bytes_per_launch"),
+                        "frac": tf / FP64_MATRIX_PEAK_TFLOPS,
+                        "useful_frac": (mfmaFlops + valuUseful) / (fusedAvgMs * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+                        "traffic": fusedTraffic, "traffic_source": pmcSource if fusedTraffic else None,
                         "mfma_flops_per_launch": mfmaFlops, "valu_fp64_flops_per_launch": valuFlops,
+                        "valu_flops_source": pmcSource if valuPerBatch else "none: profiles/pmc_fused.json has no entry",
                         "mfma_only_frac": mfmaFlops / (fusedAvgMs * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
                         "points_per_launch": fusedPts,
                         "algorithmic_hbm_bytes_per_launch": 5 * w * fusedPts,
@@ -342,6 +389,12 @@ def main():
             "lm_iters_per_s": args.steps / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "timing": {"what": "median over `segments` timed segments of exactly `steps` LM iterations each (max over "
+                               "ranks per segment); lmBegin, the bootstrap pass and lmEnd are outside the segments",
+                       "segments": int(R), "segment_ms_min": float(segTimes.min() * 1e3),
+                       "segment_ms_median": float(np.median(segTimes) * 1e3), "segment_ms_max": float(segTimes.max() * 1e3),
+                       "segment_overhead_ms": float(np.median(segOver) * 1e3),
+                       "timed_phase_s": float(tPhase)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": cfg["dtype"], "data": "synthetic",
             "config": {"workload": f"{args.workload}: {viewsPerGpu} views x {shard['pointsPerView']} pts per GPU, "
@@ -367,7 +420,9 @@ def main():
                            "error); parity with the reference is asserted on noise-free data in tests/",
                    "max_rel_err_intrinsics_vs_truth": float(np.max(np.abs(P[:L] - shard["Ptrue"][:L])
                                                                    / np.maximum(np.abs(shard["Ptrue"][:L]), 1.0)))},
-            "setup_s": {"generate": tGen, "pack_upload": tUpload, "clock_spinup_300_untimed_iterations": tSpin},
+            "setup_s": {"generate": tGen, "pack_upload": tUpload,
+                        "pack_upload_GBps": (MNlocal * 40 / tUpload / 1e9) if tUpload > 0 else None,
+                        "clock_spinup_300_untimed_iterations": tSpin},
         }
         if iters != total:
             # with the stop rule disabled lambda still overflows to inf after ~310 consecutive rejections

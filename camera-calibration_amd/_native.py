@@ -40,6 +40,13 @@ SIGNATURES = {
     "calib_lm_step_delta": (ctypes.c_int, [_h, _c_double_p, ctypes.c_double, _c_double_p]),
     "calib_refine": (ctypes.c_int, [_h, _c_double_p, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                     ctypes.c_double, ctypes.c_double, _c_double_p, _c_int_p, _c_double_p]),
+    "calib_compose_params": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p,
+                                            _c_double_p, ctypes.c_int]),
+    "calib_decompose_params": (ctypes.c_int, [ctypes.c_int, ctypes.c_int64, _c_double_p, _c_double_p, _c_double_p,
+                                              _c_double_p, ctypes.c_int]),
+    "calib_refine_awk": (ctypes.c_int, [_h, _c_double_p, _c_double_p, _c_double_p, ctypes.c_int, ctypes.c_double,
+                                        ctypes.c_double, ctypes.c_double, ctypes.c_double, _c_double_p, _c_int_p,
+                                        _c_double_p]),
     "calib_lm_begin": (ctypes.c_int, [_h, _c_double_p, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                       ctypes.c_double, ctypes.c_double]),
     "calib_lm_reduce_size": (ctypes.c_int, [_h, _c_int64_p]),
@@ -47,6 +54,7 @@ SIGNATURES = {
     "calib_lm_local": (ctypes.c_int, [_h]),
     "calib_lm_update": (ctypes.c_int, [_h]),
     "calib_lm_run": (ctypes.c_int, [_h, ctypes.c_int, ctypes.c_int]),
+    "calib_lm_run_sharded": (ctypes.c_int, [_h, ctypes.c_int, ctypes.c_int]),
     "calib_lm_done": (ctypes.c_int, [_h, _c_int_p]),
     "calib_lm_peek_trace": (ctypes.c_int, [_h, ctypes.c_int, _c_double_p, _c_int_p]),
     "calib_lm_end": (ctypes.c_int, [_h, _c_double_p, _c_double_p, _c_int_p, _c_double_p]),
@@ -65,6 +73,7 @@ SIGNATURES = {
     "calib_rccl_load": (ctypes.c_int, [ctypes.c_char_p]),
     "calib_rccl_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "calib_rccl_init": (ctypes.c_int, [_h, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "calib_rccl_init_deadline": (ctypes.c_int, [_h, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_double]),
     "calib_rccl_selftest": (ctypes.c_int, [_h, ctypes.c_double]),
     "calib_rccl_shutdown": (ctypes.c_int, [_h]),
     "calib_lm_allreduce": (ctypes.c_int, [_h]),

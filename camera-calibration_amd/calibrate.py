@@ -28,7 +28,12 @@ class Calibrator:
         self._jac = None
         self._dtype = dtype
         self._device = device
+        self._resident = engine.ResidentProblem(distortionModel.modelId, dtype, device)
         self.lastTrace = None        # (iters, 5+L) rows of the last refine (see calib_lm.h)
+
+    def close(self):
+        """release the resident engine (also happens when the Calibrator is collected)"""
+        self._resident.close()
 
     # ---- full pipeline (host initialisation + device refinement) -------------------------
     def calibrate(self, allDetections, maxIters):
@@ -84,16 +89,11 @@ class Calibrator:
         to millions of views. -> (sse, P (K,), iters, trace)"""
         if maxIters <= 0:
             raise UnboundLocalError("local variable 'Pt_error' referenced before assignment")
-        eng = engine.RefineEngine(self._distortionModel.modelId, self._dtype, self._device)
-        try:
-            eng.setProblem(viewOffsets, sensorPoints, modelPoints)
-            if not shouldPrint:
-                out = eng.refine(P0, maxIters, self._λinitial, self._λmin, self._λmax,
-                                 self._Pt_error_min)
-            else:
-                out = self._refineVerbose(eng, P0, maxIters)
-        finally:
-            eng.close()
+        eng = self._resident.get(viewOffsets, sensorPoints, modelPoints)
+        if not shouldPrint:
+            out = eng.refine(P0, maxIters, self._λinitial, self._λmin, self._λmax, self._Pt_error_min)
+        else:
+            out = self._refineVerbose(eng, P0, maxIters)
         self.lastTrace = out[3]
         return out
 
@@ -121,12 +121,8 @@ class Calibrator:
     def _computeReprojectionError(self, P, allDetections):
         """sum over points of ||sensor - projection||^2 (src/calibrate.py:178-183)"""
         offs, sensor, model = engine.packDetections(allDetections)
-        eng = engine.RefineEngine(self._distortionModel.modelId, self._dtype, self._device)
-        try:
-            eng.setProblem(offs, sensor, model)
-            return eng.evaluate(np.asarray(P, dtype=np.float64).ravel())["sse"]
-        finally:
-            eng.close()
+        eng = self._resident.get(offs, sensor, model)
+        return eng.evaluate(np.asarray(P, dtype=np.float64).ravel())["sse"]
 
     def _computeTotalError(self, ydot, y):
         """src/calibrate.py:185-188"""
@@ -135,33 +131,19 @@ class Calibrator:
     def projectAllPoints(self, P, allModelPoints):
         """(MN,2) projection of every view's model points (src/calibrate.py:190-197)"""
         offs, model = engine.packModelPoints(allModelPoints)
-        eng = engine.RefineEngine(self._distortionModel.modelId, self._dtype, self._device)
-        try:
-            eng.setProblem(offs, None, model)
-            return eng.evaluate(np.asarray(P, dtype=np.float64).ravel(), wantY=True)["y"]
-        finally:
-            eng.close()
+        eng = self._resident.get(offs, None, model)
+        return eng.evaluate(np.asarray(P, dtype=np.float64).ravel(), wantY=True)["y"]
 
-    # ---- parameter vector (host, O(M) per call) ------------------------------------------
+    # ---- parameter vector: per-view Euler (de)composition on the device -------------------
     def _composeParameterVector(self, A, W, k):
         """P = (α, β, γ, uc, vc, k..., [ρx, ρy, ρz, tx, ty, tz] per view)^T, shape (K,1);
-        rotations as Euler angles in degrees (src/calibrate.py:199-229)."""
-        A = np.asarray(A, dtype=np.float64)
-        W = np.asarray(W, dtype=np.float64).reshape(-1, 4, 4)
-        shared = np.array([A[0, 0], A[1, 1], A[0, 1], A[0, 2], A[1, 2]] + list(k), dtype=np.float64)
-        ext = np.hstack((mu.rotationMatricesToEuler(W[:, :3, :3]), W[:, :3, 3]))
-        return np.concatenate((shared, ext.ravel())).reshape(-1, 1)
+        rotations as Euler angles in degrees (src/calibrate.py:199-229), calib_compose_params."""
+        return engine.composeParameters(self._distortionModel.modelId, A, W, k, self._device).reshape(-1, 1)
 
     def _decomposeParameterVector(self, P):
-        """-> A (3,3), W list of (4,4), k (|k|,)  (src/calibrate.py:231-267)"""
-        P = np.asarray(P, dtype=np.float64).ravel()
-        numDistortionParameters = len(self._distortionModel.getDistortionSymbols())
-        start = 5 + numDistortionParameters
-        α, β, γ, uc, vc = P[:5]
-        A = np.array([[α, γ, uc], [0, β, vc], [0, 0, 1]])
-        ext = P[start:].reshape(-1, 6)
-        W = mu.posesFromRT(mu.eulerToRotationMatrices(ext[:, :3]), ext[:, 3:])
-        return A, list(W), P[5:start]
+        """-> A (3,3), W list of (4,4), k (|k|,)  (src/calibrate.py:231-267), calib_decompose_params"""
+        A, W, k = engine.decomposeParameters(self._distortionModel.modelId, P, self._device)
+        return A, list(W), k
 
     def _printIterationStats(self, iter, ts, Pt, error, λ):
         """src/calibrate.py:269-274 (A and k of the current parameters)"""

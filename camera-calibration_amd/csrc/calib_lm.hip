@@ -5,11 +5,15 @@
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <dlfcn.h>
 #include <chrono>
+#include <future>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <cstring>
 #include <new>
@@ -98,10 +102,17 @@ struct calib_handle_s {
     DevBuf<LMState> st, st_eval;
     double* red = nullptr;        // active reduce buffer (own or bound)
     void* comm = nullptr;         // RCCL communicator of the in-library all-reduce (calib_rccl_init), or null
+    DevBuf<double> rccl_test;     // operand of calib_rccl_selftest: outlives a collective that timed out
     int comm_ranks = 0, comm_rank = 0;
     bool lm_active = false;
     int lm_max_iters = 0;
     int rounds_enqueued = 0;
+
+    // pinned staging of calib_set_problem's uploads (upload_staged)
+    bool stage_ready = false;
+    hipStream_t stage_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* stage_buf[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    hipEvent_t stage_ev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
 
     // profiling
     bool prof = false;
@@ -145,12 +156,64 @@ struct RcclApi {
     int (*commAbort)(void*) = nullptr;
     const char* (*getErrorString)(int) = nullptr;
 };
-RcclApi g_rccl;
+RcclApi g_rccl;                 // written once under g_rccl_mutex (calib_rccl_load), read-only afterwards
+std::mutex g_rccl_mutex;
 constexpr int kNcclDouble = 8, kNcclSum = 0;
 
 int rccl_fail(const char* what, int rc) {
     return fail(CALIB_E_HIP, std::string(what) + ": " +
                              (g_rccl.getErrorString ? g_rccl.getErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")");
+}
+
+// ---- host -> device copies of large caller arrays --------------------------------------------
+// Pageable memory goes over PCIe at ~8 GB/s through hipMemcpy. Here kUploadThreads host threads copy
+// alternating 4 MiB chunks into their own pair of pinned buffers and DMA them from there on their own stream:
+// the host memcpy of one chunk overlaps the DMA of the previous ones.
+constexpr int kUploadThreads = 4;
+constexpr size_t kUploadChunk = (size_t)4 << 20;
+
+int upload_staged(calib_handle_s* h, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return CALIB_OK;
+    if (bytes < 2 * kUploadChunk) {
+        HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+        return CALIB_OK;
+    }
+    if (!h->stage_ready) {
+        for (int t = 0; t < kUploadThreads; ++t) {
+            HIP_TRY(hipStreamCreateWithFlags(&h->stage_stream[t], hipStreamNonBlocking));
+            for (int b = 0; b < 2; ++b) {
+                HIP_TRY(hipHostMalloc(&h->stage_buf[t][b], kUploadChunk, hipHostMallocDefault));
+                HIP_TRY(hipEventCreateWithFlags(&h->stage_ev[t][b], hipEventDisableTiming));
+            }
+        }
+        h->stage_ready = true;
+    }
+    const size_t nchunks = (bytes + kUploadChunk - 1) / kUploadChunk;
+    hipError_t errs[kUploadThreads];
+    std::thread workers[kUploadThreads];
+    for (int t = 0; t < kUploadThreads; ++t) {
+        errs[t] = hipSuccess;
+        workers[t] = std::thread([=, &errs]() {
+            hipError_t e = hipSetDevice(h->device);
+            size_t use = 0;
+            for (size_t c = (size_t)t; c < nchunks && e == hipSuccess; c += kUploadThreads, ++use) {
+                const int b = (int)(use & 1);
+                const size_t off = c * kUploadChunk, n = std::min(kUploadChunk, bytes - off);
+                if (use >= 2) e = hipEventSynchronize(h->stage_ev[t][b]);      // this buffer's previous DMA is done
+                if (e != hipSuccess) break;
+                std::memcpy(h->stage_buf[t][b], static_cast<const char*>(src) + off, n);
+                e = hipMemcpyAsync(static_cast<char*>(dst) + off, h->stage_buf[t][b], n, hipMemcpyHostToDevice,
+                                   h->stage_stream[t]);
+                if (e == hipSuccess) e = hipEventRecord(h->stage_ev[t][b], h->stage_stream[t]);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stage_stream[t]);
+            errs[t] = e;
+        });
+    }
+    for (auto& w : workers) w.join();
+    for (int t = 0; t < kUploadThreads; ++t)
+        if (errs[t] != hipSuccess) return fail(CALIB_E_HIP, std::string("staged upload: ") + hipGetErrorString(errs[t]));
+    return CALIB_OK;
 }
 
 // ---- launches ---------------------------------------------------------------------------
@@ -386,13 +449,21 @@ int calib_destroy(calib_handle_t h) {
     (void)hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.commDestroy) { (void)g_rccl.commDestroy(h->comm); h->comm = nullptr; }
     for (auto& e : h->ev) (void)hipEventDestroy(e);
+    if (h->stage_ready)
+        for (int t = 0; t < 4; ++t) {
+            for (int b = 0; b < 2; ++b) {
+                if (h->stage_ev[t][b]) (void)hipEventDestroy(h->stage_ev[t][b]);
+                if (h->stage_buf[t][b]) (void)hipHostFree(h->stage_buf[t][b]);
+            }
+            if (h->stage_stream[t]) (void)hipStreamDestroy(h->stage_stream[t]);
+        }
     h->uv.release(); h->XY.release(); h->Z.release(); h->VC.release(); h->J.release();
     h->r.release(); h->y.release(); h->pt_view.release(); h->view_ext.release();
     h->item_n.release(); h->view_item0.release(); h->item_view.release(); h->item_pt0.release(); h->sse_part.release();
     h->emit_tab.release();
     h->G[0].release(); h->G[1].release(); h->bpart.release(); h->part.release(); h->red_own.release();
     h->P[0].release(); h->P[1].release(); h->Peval.release(); h->trace.release();
-    h->st.release(); h->st_eval.release();
+    h->st.release(); h->st_eval.release(); h->rccl_test.release();
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return CALIB_OK;
@@ -443,16 +514,18 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
     h->M = num_views;
     h->MN = MN;
 
-    // host-side packing: SoA + compact (non-empty) view list + gram work items
-    std::vector<int> pt_view((size_t)MN), view_ext, item_n, view_item0, item_view;
-    std::vector<int64_t> item_pt0;
+    // host side, O(views): compact (non-empty) view list, their point offsets, gram / fused work items.
+    // Everything O(points) -- the AoS -> SoA split, the storage-type conversion, the point -> view index --
+    // happens on the device from the caller's arrays uploaded as they are (pack_points_kernel).
+    std::vector<int> view_ext, item_n, view_item0, item_view;
+    std::vector<int64_t> item_pt0, voffs;
     view_item0.push_back(0);
     for (int64_t i = 0; i < num_views; ++i) {
         const int64_t a = view_offsets[i], b = view_offsets[i + 1];
         if (b == a) continue;
         const int cv = (int)view_ext.size();
         view_ext.push_back((int)i);
-        for (int64_t p = a; p < b; ++p) pt_view[(size_t)p] = cv;
+        voffs.push_back(a);
         for (int64_t p = a; p < b; p += kGramChunk) {
             item_pt0.push_back(p);
             item_n.push_back((int)std::min<int64_t>(kGramChunk, b - p));
@@ -460,8 +533,11 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
         }
         view_item0.push_back((int)item_pt0.size());
     }
+    voffs.push_back(MN);
     h->nv = (int)view_ext.size();
     h->n_items = (int)item_pt0.size();
+    // compact view of point p (points of the non-empty views are contiguous)
+    auto viewOf = [&](int64_t p) { return (int)(std::upper_bound(voffs.begin(), voffs.end(), p) - voffs.begin()) - 1; };
     {   // waves per gram item from the mean points per item: a wave wants >= 2 trips of 16 points
         const double avg = h->n_items ? (double)MN / h->n_items : 0.0;
         h->gram_wpi = avg >= 128 ? 4 : (avg >= 64 ? 2 : 1);
@@ -475,9 +551,15 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
     }
     h->n_tiles = (MN + kTile - 1) / kTile;
     int mv = 1;
-    for (int64_t t = 0; t < h->n_tiles; ++t) {
-        const int64_t a = t * kTile, b = std::min<int64_t>(MN, a + kTile) - 1;
-        mv = std::max(mv, pt_view[(size_t)b] - pt_view[(size_t)a] + 1);
+    {   // views spanned by a 256-point tile (what the jacobian kernel stages in LDS): one sweep over the offsets
+        int va = 0, vb = 0;
+        for (int64_t t = 0; t < h->n_tiles; ++t) {
+            const int64_t a = t * kTile, b = std::min<int64_t>(MN, a + kTile) - 1;
+            while (voffs[(size_t)va + 1] <= a) ++va;
+            if (vb < va) vb = va;
+            while (voffs[(size_t)vb + 1] <= b) ++vb;
+            mv = std::max(mv, vb - va + 1);
+        }
     }
     {   // chunks of whole views, ~chunk_points each; tiles of a chunk start at the chunk's first point
         // Measured on MI355X (c3, 2 M points): chunks small enough for the 256 MiB Infinity Cache
@@ -500,12 +582,14 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
             }
             c.p1 = p1;
             c.item1 = view_item0[(size_t)v];
+            const bool whole = h->chunks.empty() && v >= h->nv;       // one chunk = the tiles counted above
             h->chunks.push_back(c);
             h->max_chunk_points = std::max(h->max_chunk_points, c.p1 - c.p0);
-            for (int64_t a = c.p0; a < c.p1; a += kTile) {
-                const int64_t b = std::min<int64_t>(c.p1, a + kTile) - 1;
-                mv = std::max(mv, pt_view[(size_t)b] - pt_view[(size_t)a] + 1);
-            }
+            if (!whole)
+                for (int64_t a = c.p0; a < c.p1; a += kTile) {
+                    const int64_t b = std::min<int64_t>(c.p1, a + kTile) - 1;
+                    mv = std::max(mv, viewOf(b) - viewOf(a) + 1);
+                }
         }
     }
     h->max_views_per_tile = mv;
@@ -533,32 +617,44 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
         if (bytes == 0) return hipSuccess;
         return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
     };
-    if (h->dtype == CALIB_DTYPE_F64) {
-        std::vector<double> xy((size_t)MN * 2), z((size_t)MN);
-        for (int64_t p = 0; p < MN; ++p) {
-            xy[2 * p] = model_xyz[3 * p]; xy[2 * p + 1] = model_xyz[3 * p + 1]; z[p] = model_xyz[3 * p + 2];
-        }
-        HIP_TRY(upload(h->XY.p, xy.data(), xy.size() * 8));
-        HIP_TRY(upload(h->Z.p, z.data(), z.size() * 8));
-        if (sensor_uv) HIP_TRY(upload(h->uv.p, sensor_uv, (size_t)MN * 16));
-        else if (MN) HIP_TRY(hipMemset(h->uv.p, 0, (size_t)MN * 16));
-    } else {
-        std::vector<float> xy((size_t)MN * 2), z((size_t)MN), uv((size_t)MN * 2, 0.f);
-        for (int64_t p = 0; p < MN; ++p) {
-            xy[2 * p] = (float)model_xyz[3 * p]; xy[2 * p + 1] = (float)model_xyz[3 * p + 1];
-            z[p] = (float)model_xyz[3 * p + 2];
-            if (sensor_uv) { uv[2 * p] = (float)sensor_uv[2 * p]; uv[2 * p + 1] = (float)sensor_uv[2 * p + 1]; }
-        }
-        HIP_TRY(upload(h->XY.p, xy.data(), xy.size() * 4));
-        HIP_TRY(upload(h->Z.p, z.data(), z.size() * 4));
-        HIP_TRY(upload(h->uv.p, uv.data(), uv.size() * 4));
-    }
-    HIP_TRY(upload(h->pt_view.p, pt_view.data(), pt_view.size() * 4));
     HIP_TRY(upload(h->view_ext.p, view_ext.data(), view_ext.size() * 4));
     HIP_TRY(upload(h->item_n.p, item_n.data(), item_n.size() * 4));
     HIP_TRY(upload(h->item_view.p, item_view.data(), item_view.size() * 4));
     HIP_TRY(upload(h->item_pt0.p, item_pt0.data(), item_pt0.size() * 8));
     HIP_TRY(upload(h->view_item0.p, view_item0.data(), view_item0.size() * 4));
+    if (MN > 0) {
+        DevBuf<double> xyz_stage, uv_stage;
+        DevBuf<int64_t> dvoffs;
+        HIP_TRY(xyz_stage.alloc((size_t)MN * 3));
+        HIP_TRY(dvoffs.alloc(voffs.size()));
+        HIP_TRY(upload(dvoffs.p, voffs.data(), voffs.size() * 8));
+        int rc = upload_staged(h, xyz_stage.p, model_xyz, (size_t)MN * 24);
+        if (rc) return rc;
+        int uv_mode = 2;
+        const double* uv_in = nullptr;
+        if (sensor_uv && h->dtype == CALIB_DTYPE_F64) {             // already in the device layout
+            rc = upload_staged(h, h->uv.p, sensor_uv, (size_t)MN * 16);
+            if (rc) return rc;
+            uv_mode = 0;
+        } else if (sensor_uv) {
+            HIP_TRY(uv_stage.alloc((size_t)MN * 2));
+            rc = upload_staged(h, uv_stage.p, sensor_uv, (size_t)MN * 16);
+            if (rc) return rc;
+            uv_in = uv_stage.p;
+            uv_mode = 1;
+        }
+        const unsigned blocks = (unsigned)((MN + 255) / 256);
+        if (h->dtype == CALIB_DTYPE_F64)
+            hipLaunchKernelGGL((pack_points_kernel<double>), dim3(blocks), dim3(256), 0, h->stream, xyz_stage.p, uv_in,
+                               uv_mode, dvoffs.p, h->nv, MN, reinterpret_cast<double2*>(h->XY.p),
+                               reinterpret_cast<double*>(h->Z.p), reinterpret_cast<double2*>(h->uv.p), h->pt_view.p);
+        else
+            hipLaunchKernelGGL((pack_points_kernel<float>), dim3(blocks), dim3(256), 0, h->stream, xyz_stage.p, uv_in,
+                               uv_mode, dvoffs.p, h->nv, MN, reinterpret_cast<float2*>(h->XY.p),
+                               reinterpret_cast<float*>(h->Z.p), reinterpret_cast<float2*>(h->uv.p), h->pt_view.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(h->stream));                   // the staging buffers go out of scope
+    }
     h->has_problem = true;
     return CALIB_OK;
 }
@@ -643,7 +739,9 @@ int calib_lm_begin(calib_handle_t h, const double* P0, int max_iters, double lam
     if (max_iters <= 0)
         return fail(CALIB_E_INVALID, "max_iters must be >= 1 (the reference raises UnboundLocalError "
                                      "for maxIters=0, src/calibrate.py:171)");
-    if (h->M == 0) return fail(CALIB_E_INVALID, "no views to refine");
+    // A shard WITHOUT views is legal (ranks of a sharded run may own none): it contributes zeros to the
+    // reduce buffer and still takes every decision. Alone, it ends as the reference does on an empty system:
+    // CALIB_E_SINGULAR from the L x L solve.
     if (h->nv != h->M)
         return fail(CALIB_E_SINGULAR, "a view without points makes J^T J + lambda diag(J^T J) singular");
     const size_t ts = tsize(h);
@@ -732,13 +830,25 @@ int calib_lm_peek_trace(calib_handle_t h, int iter, double* out_row, int* out_it
     return CALIB_OK;
 }
 
-int calib_lm_run(calib_handle_t h, int rounds, int check_every) {
+namespace {
+int lm_run(calib_handle_t h, int rounds, int check_every, bool sharded);
+}
+
+int calib_lm_run(calib_handle_t h, int rounds, int check_every) { return lm_run(h, rounds, check_every, false); }
+
+int calib_lm_run_sharded(calib_handle_t h, int rounds, int check_every) {
+    if (h && !h->comm) return fail(CALIB_E_STATE, "calib_rccl_init has not been called");
+    return lm_run(h, rounds, check_every, true);
+}
+
+namespace {
+int lm_run(calib_handle_t h, int rounds, int check_every, bool sharded) {
     CHECK_H(h);
     if (!h->lm_active) return fail(CALIB_E_STATE, "calib_lm_begin has not been called");
     for (int i = 0; i < rounds; ++i) {
         int rc = calib_lm_local(h);
         if (rc) return rc;
-        if (h->comm) {
+        if (sharded) {
             rc = calib_lm_allreduce(h);
             if (rc) return rc;
         }
@@ -753,8 +863,10 @@ int calib_lm_run(calib_handle_t h, int rounds, int check_every) {
     }
     return CALIB_OK;
 }
+}  // namespace
 
 int calib_rccl_load(const char* librccl_path) {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.lib) return CALIB_OK;
     if (!librccl_path) return fail(CALIB_E_INVALID, "librccl path is null");
     void* lib = dlopen(librccl_path, RTLD_NOW | RTLD_GLOBAL);
@@ -767,8 +879,10 @@ int calib_rccl_load(const char* librccl_path) {
     a.commDestroy = reinterpret_cast<decltype(a.commDestroy)>(dlsym(lib, "ncclCommDestroy"));
     a.commAbort = reinterpret_cast<decltype(a.commAbort)>(dlsym(lib, "ncclCommAbort"));
     a.getErrorString = reinterpret_cast<decltype(a.getErrorString)>(dlsym(lib, "ncclGetErrorString"));
-    if (!a.getUniqueId || !a.commInitRank || !a.allReduce || !a.commDestroy || !a.commAbort)
+    if (!a.getUniqueId || !a.commInitRank || !a.allReduce || !a.commDestroy || !a.commAbort) {
+        (void)dlclose(lib);
         return fail(CALIB_E_HIP, "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy / ncclCommAbort");
+    }
     g_rccl = a;
     return CALIB_OK;
 }
@@ -784,16 +898,35 @@ int calib_rccl_unique_id(void* out_id128) {
 }
 
 int calib_rccl_init(calib_handle_t h, int nranks, int rank, const void* id128) {
+    return calib_rccl_init_deadline(h, nranks, rank, id128, 120.0);
+}
+
+int calib_rccl_init_deadline(calib_handle_t h, int nranks, int rank, const void* id128, double timeout_s) {
     CHECK_H(h);
     if (!g_rccl.lib) return fail(CALIB_E_STATE, "calib_rccl_load has not been called");
     if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(CALIB_E_INVALID, "bad communicator arguments");
     if (h->comm) return fail(CALIB_E_STATE, "this handle already has a communicator");
-    RcclId id;
-    std::memcpy(id.internal, id128, sizeof(id.internal));
-    void* comm = nullptr;
-    const int rc = g_rccl.commInitRank(&comm, nranks, id, rank);
-    if (rc) return rccl_fail("ncclCommInitRank", rc);
-    h->comm = comm;
+    // ncclCommInitRank blocks until every rank has joined; a peer that never calls it would hang this thread
+    // for good. It runs on a helper thread; past the deadline the caller gets an error and the helper, should
+    // it ever return, destroys the communicator it made.
+    struct Job { RcclId id; int nranks, rank, device; void* comm = nullptr; int rc = 0; std::atomic<bool> abandoned{false}; };
+    auto job = std::make_shared<Job>();
+    std::memcpy(job->id.internal, id128, sizeof(job->id.internal));
+    job->nranks = nranks; job->rank = rank; job->device = h->device;
+    std::promise<void> donePromise;
+    std::future<void> done = donePromise.get_future();
+    std::thread([job, p = std::move(donePromise)]() mutable {
+        (void)hipSetDevice(job->device);
+        job->rc = g_rccl.commInitRank(&job->comm, job->nranks, job->id, job->rank);
+        if (job->abandoned.load() && job->rc == 0 && job->comm) (void)g_rccl.commAbort(job->comm);
+        p.set_value();
+    }).detach();
+    if (done.wait_for(std::chrono::duration<double>(timeout_s > 0 ? timeout_s : 120.0)) != std::future_status::ready) {
+        job->abandoned.store(true);
+        return fail(CALIB_E_HIP, "ncclCommInitRank did not return before the deadline (a peer rank is missing)");
+    }
+    if (job->rc) return rccl_fail("ncclCommInitRank", job->rc);
+    h->comm = job->comm;
     h->comm_ranks = nranks;
     h->comm_rank = rank;
     return CALIB_OK;
@@ -813,36 +946,36 @@ int calib_rccl_shutdown(calib_handle_t h) {
 int calib_rccl_selftest(calib_handle_t h, double timeout_s) {
     CHECK_H(h);
     if (!h->comm) return fail(CALIB_E_STATE, "calib_rccl_init has not been called");
-    // rank r contributes (r + 1, 1, 2^r, 4): the sums must come back as (n (n + 1) / 2, n, 2^n - 1, 4 n)
+    // rank r contributes (r + 1, 1, 2^r, 4): the sums must come back as (n (n + 1) / 2, n, 2^n - 1, 4 n).
+    // The operand lives in the handle: a collective that timed out may still refer to it.
     const int n = h->comm_ranks, r = h->comm_rank;
-    DevBuf<double> buf;
-    HIP_TRY(buf.alloc(4));
+    HIP_TRY(h->rccl_test.alloc(4));
     const double mine[4] = {r + 1.0, 1.0, std::ldexp(1.0, r), 4.0};
     const double want[4] = {0.5 * n * (n + 1.0), (double)n, std::ldexp(1.0, n) - 1.0, 4.0 * n};
-    hipError_t e = hipMemcpy(buf.p, mine, sizeof(mine), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { buf.release(); return fail(CALIB_E_HIP, hipGetErrorString(e)); }
-    int rc = g_rccl.allReduce(buf.p, buf.p, 4, kNcclDouble, kNcclSum, h->comm, h->stream);
-    if (rc) { buf.release(); return rccl_fail("ncclAllReduce (self-test)", rc); }
+    HIP_TRY(hipMemcpy(h->rccl_test.p, mine, sizeof(mine), hipMemcpyHostToDevice));
+    auto giveUp = [&]() {                   // the communicator cannot be trusted: abort it, never destroy it
+        (void)g_rccl.commAbort(h->comm);
+        h->comm = nullptr;
+        h->comm_ranks = 0;
+    };
+    int rc = g_rccl.allReduce(h->rccl_test.p, h->rccl_test.p, 4, kNcclDouble, kNcclSum, h->comm, h->stream);
+    if (rc) { giveUp(); return rccl_fail("ncclAllReduce (self-test)", rc); }
     const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(timeout_s > 0 ? timeout_s : 30.0);
     for (;;) {
-        e = hipStreamQuery(h->stream);
+        const hipError_t e = hipStreamQuery(h->stream);
         if (e == hipSuccess) break;
-        if (e != hipErrorNotReady) { buf.release(); return fail(CALIB_E_HIP, hipGetErrorString(e)); }
+        if (e != hipErrorNotReady) { giveUp(); return fail(CALIB_E_HIP, hipGetErrorString(e)); }
         if (std::chrono::steady_clock::now() > deadline) {
-            (void)g_rccl.commAbort(h->comm);        // the collective never completed: give the communicator up
-            h->comm = nullptr;
-            h->comm_ranks = 0;
+            giveUp();
             return fail(CALIB_E_HIP, "in-library all-reduce self-test timed out");
         }
         std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
     double got[4] = {0, 0, 0, 0};
-    e = hipMemcpy(got, buf.p, sizeof(got), hipMemcpyDeviceToHost);
-    buf.release();
-    if (e != hipSuccess) return fail(CALIB_E_HIP, hipGetErrorString(e));
+    HIP_TRY(hipMemcpy(got, h->rccl_test.p, sizeof(got), hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; ++i)
         if (got[i] != want[i]) {
-            (void)calib_rccl_shutdown(h);
+            giveUp();
             return fail(CALIB_E_HIP, "in-library all-reduce self-test returned wrong sums");
         }
     return CALIB_OK;
@@ -1164,6 +1297,69 @@ int calib_distortion_normal_equations(int model, int64_t num_views, const int64_
         for (int b2 = a2; b2 < nk; ++b2) { out_DtD[a2 * nk + b2] = sum[(size_t)idx]; out_DtD[b2 * nk + a2] = sum[(size_t)idx]; ++idx; }
     for (int a2 = 0; a2 < nk; ++a2) out_Dtd[a2] = sum[(size_t)idx++];
     return CALIB_OK;
+}
+
+namespace {
+int num_distortion(int model) { return model == CALIB_MODEL_RADTAN ? 5 : 4; }
+}
+
+int calib_compose_params(int model, int64_t num_views, const double* A, const double* W, const double* k,
+                         double* P_out, int device_id) {
+    if (model != CALIB_MODEL_RADTAN && model != CALIB_MODEL_FISHEYE) return fail(CALIB_E_INVALID, "unknown distortion model");
+    if (num_views < 0 || !A || !k || !P_out || (num_views > 0 && !W)) return fail(CALIB_E_INVALID, "null argument");
+    const int nk = num_distortion(model), L = 5 + nk;
+    // shared part: (alpha, beta, gamma, uc, vc, k...) from A = [[alpha, gamma, uc], [0, beta, vc], [0, 0, 1]]
+    P_out[0] = A[0]; P_out[1] = A[4]; P_out[2] = A[1]; P_out[3] = A[2]; P_out[4] = A[5];
+    for (int j = 0; j < nk; ++j) P_out[5 + j] = k[j];
+    if (num_views == 0) return CALIB_OK;
+    int rc = use_device(device_id);
+    if (rc) return rc;
+    DevBuf<double> dW, dP;
+    HIP_TRY(dW.alloc((size_t)num_views * 16));
+    HIP_TRY(dP.alloc((size_t)L + 6 * (size_t)num_views));
+    HIP_TRY(hipMemcpy(dW.p, W, (size_t)num_views * 128, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(compose_views_kernel, dim3((unsigned)((num_views + 255) / 256)), dim3(256), 0, 0, dW.p, num_views, L, dP.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(P_out + L, dP.p + L, (size_t)num_views * 48, hipMemcpyDeviceToHost));
+    return CALIB_OK;
+}
+
+int calib_decompose_params(int model, int64_t num_views, const double* P, double* A_out, double* W_out,
+                           double* k_out, int device_id) {
+    if (model != CALIB_MODEL_RADTAN && model != CALIB_MODEL_FISHEYE) return fail(CALIB_E_INVALID, "unknown distortion model");
+    if (num_views < 0 || !P || (num_views > 0 && !W_out)) return fail(CALIB_E_INVALID, "null argument");
+    const int nk = num_distortion(model), L = 5 + nk;
+    if (A_out) {
+        const double a[9] = {P[0], P[2], P[3], 0.0, P[1], P[4], 0.0, 0.0, 1.0};
+        std::memcpy(A_out, a, sizeof(a));
+    }
+    if (k_out) for (int j = 0; j < nk; ++j) k_out[j] = P[5 + j];
+    if (num_views == 0) return CALIB_OK;
+    int rc = use_device(device_id);
+    if (rc) return rc;
+    DevBuf<double> dW, dP;
+    HIP_TRY(dW.alloc((size_t)num_views * 16));
+    HIP_TRY(dP.alloc((size_t)L + 6 * (size_t)num_views));
+    HIP_TRY(hipMemcpy(dP.p, P, ((size_t)L + 6 * (size_t)num_views) * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(decompose_views_kernel, dim3((unsigned)((num_views + 255) / 256)), dim3(256), 0, 0, dP.p, num_views, L, dW.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(W_out, dW.p, (size_t)num_views * 128, hipMemcpyDeviceToHost));
+    return CALIB_OK;
+}
+
+int calib_refine_awk(calib_handle_t h, double* A_inout, double* W_inout, double* k_inout, int max_iters,
+                     double lam_init, double lam_min, double lam_max, double err_min, double* out_sse,
+                     int* out_iters, double* out_trace) {
+    CHECK_H(h);
+    int rc = need_problem(h);
+    if (rc) return rc;
+    if (!A_inout || !k_inout || (h->M > 0 && !W_inout)) return fail(CALIB_E_INVALID, "null argument");
+    std::vector<double> P((size_t)numParams(h));
+    rc = calib_compose_params(h->model, h->M, A_inout, W_inout, k_inout, P.data(), h->device);
+    if (rc) return rc;
+    rc = calib_refine(h, P.data(), max_iters, lam_init, lam_min, lam_max, err_min, out_sse, out_iters, out_trace);
+    if (rc) return rc;
+    return calib_decompose_params(h->model, h->M, P.data(), A_inout, W_inout, k_inout, h->device);
 }
 
 int calib_profile_enable(calib_handle_t h, int on) {

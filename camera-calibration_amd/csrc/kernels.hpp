@@ -1416,6 +1416,83 @@ __global__ __launch_bounds__(256) void distortion_normal_kernel(const double* __
         part[(int64_t)blockIdx.x * NS + threadIdx.x] = (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
 }
 
+// ---------------------------------------------------------------- problem packing
+// calib_set_problem uploads the caller's (MN,3) model points and (MN,2) sensor points as they are; this kernel
+// splits them into the SoA layout of the point kernels (XY pairs, Z, uv pairs, in the storage type T) and
+// writes every point's compact view index (binary search in the offsets of the non-empty views).
+template <typename T>
+__global__ __launch_bounds__(256) void pack_points_kernel(const double* __restrict__ xyz, const double* __restrict__ uv_in,
+                                                          int uv_mode /* 0: leave, 1: convert uv_in, 2: zeros */,
+                                                          const int64_t* __restrict__ voffs, int nv, int64_t MN,
+                                                          typename Pair<T>::type* __restrict__ XY, T* __restrict__ Z,
+                                                          typename Pair<T>::type* __restrict__ uv, int* __restrict__ pt_view) {
+    using T2 = typename Pair<T>::type;
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= MN) return;
+    T2 xy;
+    xy.x = (T)xyz[3 * p]; xy.y = (T)xyz[3 * p + 1];
+    XY[p] = xy;
+    Z[p] = (T)xyz[3 * p + 2];
+    if (uv_mode == 1) { T2 m; m.x = (T)uv_in[2 * p]; m.y = (T)uv_in[2 * p + 1]; uv[p] = m; }
+    else if (uv_mode == 2) { T2 m; m.x = T(0); m.y = T(0); uv[p] = m; }
+    int lo = 0, hi = nv;                       // voffs[lo] <= p < voffs[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (voffs[mid] <= p) lo = mid; else hi = mid;
+    }
+    pt_view[p] = lo;
+}
+
+// ---------------------------------------------------------------- parameter vector (de)composition
+// Calibrator._composeParameterVector / _decomposeParameterVector (src/calibrate.py:199-267), the per-view part:
+// world-to-camera pose W (4x4) <-> (rho_x, rho_y, rho_z [degrees], t). One thread per view.
+// Rotation -> Euler angles: Slabaugh's decomposition with the gimbal-lock branches of src/mathutils.py:13-33;
+// np.isclose(R31, +-1) there is |R31 -+ 1| <= 1e-8 + 1e-5.
+__global__ void compose_views_kernel(const double* __restrict__ W, int64_t M, int L, double* __restrict__ P) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= M) return;
+    const double* w = W + v * 16;
+    const double R11 = w[0], R12 = w[1], R13 = w[2], R21 = w[4], R31 = w[8], R32 = w[9], R33 = w[10];
+    const double tol = 1e-8 + 1e-5;
+    const double rad2deg = 57.29577951308232;
+    double psi, theta, phi;
+    if (fabs(R31 - 1.0) <= tol) {
+        phi = 0.0; theta = -1.5707963267948966; psi = atan2(-R12, -R13);
+    } else if (fabs(R31 + 1.0) <= tol) {
+        phi = 0.0; theta = 1.5707963267948966; psi = atan2(R12, R13);
+    } else {
+        theta = -asin(R31);
+        const double ct = cos(theta);
+        psi = atan2(R32 / ct, R33 / ct);
+        phi = atan2(R21 / ct, R11 / ct);
+    }
+    double* o = P + L + 6 * v;
+    o[0] = psi * rad2deg; o[1] = theta * rad2deg; o[2] = phi * rad2deg;
+    o[3] = w[3]; o[4] = w[7]; o[5] = w[11];
+}
+
+// Euler angles (degrees) -> R = Rz Ry Rx with the reference's numeric Rodrigues quirk (an angle with
+// |theta| <= 1e-8 rad is the identity, src/mathutils.py:72-79), as view_setup_kernel; W = [R t; 0 0 0 1]
+__global__ void decompose_views_kernel(const double* __restrict__ P, int64_t M, int L, double* __restrict__ W) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= M) return;
+    const double* e = P + L + 6 * v;
+    const double deg = 0.017453292519943295;
+    double s[3], c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double th = e[a] * deg;
+        sincos(th, &s[a], &c[a]);
+        if (fabs(th) <= 1e-8) { s[a] = 0.0; c[a] = 1.0; }
+    }
+    const double sx = s[0], cx = c[0], sy = s[1], cy = c[1], sz = s[2], cz = c[2];
+    double* o = W + v * 16;
+    o[0] = cz * cy;  o[1] = cz * sy * sx - sz * cx;  o[2] = cz * sy * cx + sz * sx;  o[3] = e[3];
+    o[4] = sz * cy;  o[5] = sz * sy * sx + cz * cx;  o[6] = sz * sy * cx - cz * sx;  o[7] = e[4];
+    o[8] = -sy;      o[9] = cy * sx;                 o[10] = cy * cx;                o[11] = e[5];
+    o[12] = 0.0; o[13] = 0.0; o[14] = 0.0; o[15] = 1.0;
+}
+
 // ---------------------------------------------------------------- small forward-model kernels
 template <int MODEL>
 __global__ void distort_points_kernel(const double* __restrict__ xn, const double* __restrict__ k,

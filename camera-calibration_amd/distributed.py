@@ -4,7 +4,7 @@ Rows of J belonging to different views are independent given P, and a view's six
 extrinsics appear only in its own rows (src/jacobian.py:81-83), so each rank keeps a
 contiguous range of views resident in its HBM and eliminates their 6x6 blocks locally.
 What is shared is the L x L Schur system: per LM round every rank contributes its partial
-sums (reduce buffer of calib_lm.h, 443 doubles for L = 10) to ONE sum all-reduce (RCCL over
+sums (reduce buffer of calib_lm.h: 444 doubles for L = 10, 364 for L = 9) to ONE sum all-reduce (RCCL over
 xGMI through torch.distributed), after which every rank takes the identical accept/reject
 decision and solves the identical L x L system redundantly. No other data-path collective.
 
@@ -15,8 +15,9 @@ import numpy as np
 
 
 def partitionViews(viewOffsets, worldSize):
-    """Contiguous view ranges balanced by point count.
-    -> list of (viewStart, viewEnd) per rank (possibly empty ranges when M < worldSize)."""
+    """Contiguous view ranges balanced by point count -> list of (viewStart, viewEnd) per rank.
+    Every rank gets at least one view when there are at least worldSize views; with fewer views the
+    surplus ranks get empty ranges (an empty shard contributes zeros and follows every decision)."""
     offs = np.asarray(viewOffsets, dtype=np.int64)
     M = offs.shape[0] - 1
     total = int(offs[-1])
@@ -27,10 +28,25 @@ def partitionViews(viewOffsets, worldSize):
         # pick the boundary whose point offset is closest to the target
         if v > 0 and abs(int(offs[v - 1]) - target) <= abs(int(offs[min(v, M)]) - target):
             v -= 1
-        v = min(max(v, bounds[-1]), M)
-        bounds.append(v)
+        if M >= worldSize:
+            lo, hi = bounds[-1] + 1, M - (worldSize - r)      # leave a view for this rank and for each later one
+        else:
+            lo, hi = bounds[-1], M
+        bounds.append(min(max(v, lo), hi))
     bounds.append(M)
     return [(bounds[r], bounds[r + 1]) for r in range(worldSize)]
+
+
+def validateGlobalProblem(viewOffsets):
+    """What a single engine would reject, checked on the GLOBAL offsets every rank holds, so that all ranks
+    raise together instead of one of them leaving the others inside the per-round all-reduce."""
+    offs = np.asarray(viewOffsets, dtype=np.int64)
+    if offs.ndim != 1 or offs.shape[0] < 2:
+        raise ValueError("no views to refine")
+    if offs[0] != 0 or np.any(np.diff(offs) < 0):
+        raise ValueError("view_offsets must start at 0 and be non-decreasing")
+    if np.any(np.diff(offs) == 0):
+        raise np.linalg.LinAlgError("a view without points makes J^T J + lambda diag(J^T J) singular")
 
 
 def shardProblem(P, viewOffsets, sensorPoints, modelPoints, L, viewRange):
@@ -67,7 +83,7 @@ class ShardedLM:
         rank) done flag is read every checkEvery rounds and the loop stops early."""
         if getattr(self.allReduce, "inLibrary", False):
             # the library all-reduces between its local and update steps itself: whole rounds from C
-            self.eng.lmRun(int(rounds), int(checkEvery))
+            self.eng.lmRunSharded(int(rounds), int(checkEvery))
             return
         for i in range(int(rounds)):
             self.round()
@@ -105,7 +121,7 @@ def directAllReduce(eng, timeoutSeconds=30.0):
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
-    dev = torch.device("cuda", torch.cuda.current_device())
+    dev = torch.device("cuda", getattr(eng, "device", torch.cuda.current_device()))      # the ENGINE's device
 
     def allRanksOk(ok):
         t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -148,6 +164,17 @@ def directAllReduce(eng, timeoutSeconds=30.0):
     return allReduce
 
 
+def _raiseTogether(dist, torch, err, device):
+    """MIN-reduce an ok flag: a rank whose local step failed re-raises its error, every other rank raises too --
+    nobody is left waiting in a later collective."""
+    ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if err is not None:
+        raise err
+    if int(ok.item()) == 0:
+        raise RuntimeError("refineDistributed: another rank rejected its shard; see that rank's error")
+
+
 def refineDistributed(modelName, P0, viewOffsets, sensorPoints, modelPoints, maxIters, dtype="f64",
                       checkEvery=8, engineFactory=None, allReduceFactory=None, **lmOptions):
     """Refine ONE global problem with the views sharded over the ranks of the default
@@ -163,23 +190,46 @@ def refineDistributed(modelName, P0, viewOffsets, sensorPoints, modelPoints, max
     from . import engine as engine_mod
     rank, world = dist.get_rank(), dist.get_world_size()
     L = engine_mod.NUM_SHARED[engine_mod.MODEL_IDS[modelName]]
+    validateGlobalProblem(viewOffsets)                 # identical on every rank: everybody raises, or nobody
+    if int(maxIters) <= 0:
+        raise UnboundLocalError("local variable 'Pt_error' referenced before assignment (maxIters=0)")
     parts = partitionViews(viewOffsets, world)
     Pl, ol, sl, ml = shardProblem(P0, viewOffsets, sensorPoints, modelPoints, L, parts[rank])
-    if engineFactory is None:
-        local = int(os.environ.get("LOCAL_RANK", rank))
-        eng = engine_mod.RefineEngine(modelName, dtype, local)
-        eng.setProblem(ol, sl, ml)
-        allReduce = None
+    onGpu = engineFactory is None
+    okDevice = "cpu"
+    eng = allReduce = None
+    err = None
+    try:
+        if onGpu:
+            local = int(os.environ.get("LOCAL_RANK", rank))
+            torch.cuda.set_device(local)
+            if dist.get_backend() == "nccl":
+                okDevice = torch.device("cuda", local)
+            eng = engine_mod.RefineEngine(modelName, dtype, local)
+            eng.setProblem(ol, sl, ml)
+        else:
+            eng = engineFactory(ol, sl, ml)
+    except Exception as e:           # noqa: BLE001 -- re-raised below, after every rank knows
+        err = e
+    _raiseTogether(dist, torch, err, okDevice)
+    if onGpu:
         # CALIB_ALLREDUCE=direct|auto: the library issues ncclAllReduce itself (self-tested; torch otherwise)
         if os.environ.get("CALIB_ALLREDUCE", "torch") != "torch" and dist.get_backend() == "nccl":
             allReduce = directAllReduce(eng)
         if allReduce is None:
-            allReduce = torchAllReduce(eng, torch.device("cuda", local))
+            allReduce = torchAllReduce(eng, torch.device("cuda", eng.device))
     else:
-        eng = engineFactory(ol, sl, ml)
         allReduce = allReduceFactory(eng)
     lm = ShardedLM(eng, allReduce)
-    lm.begin(Pl, maxIters, **lmOptions)
+    # begin = lmBegin (may reject this rank's shard) + round 0 (first collective): the rejection is agreed on
+    # before anybody enters the collective
+    try:
+        lm.maxIters = int(maxIters)
+        eng.lmBegin(Pl, maxIters, **lmOptions)
+    except Exception as e:           # noqa: BLE001
+        err = e
+    _raiseTogether(dist, torch, err, okDevice)
+    lm.round()
     lm.run(maxIters, checkEvery=checkEvery)
     sse, Plocal, iters, trace = lm.end()
     # assemble the global parameter vector: shared part is replicated, extrinsics are gathered

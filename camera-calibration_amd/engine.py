@@ -59,6 +59,7 @@ class RefineEngine:
     def __init__(self, model, dtype="f64", device=0):
         self._lib = nat.loadLibrary()
         nat.requireDevice()
+        self.device = int(device)
         self.modelId = MODEL_IDS[model] if isinstance(model, str) else int(model)
         self.dtypeId = DTYPE_IDS[dtype] if isinstance(dtype, str) else int(dtype)
         self.L = NUM_SHARED[self.modelId]
@@ -170,6 +171,27 @@ class RefineEngine:
                                          ctypes.byref(iters), nat.dptr(trace)))
         return sse.value, P, iters.value, trace[:iters.value]
 
+    def refineAWk(self, A, W, k, maxIters, lamInit=LAMBDA_INITIAL, lamMin=LAMBDA_MIN, lamMax=LAMBDA_MAX,
+                  errMin=PT_ERROR_MIN):
+        """(A, W, k) in, refined (A, W, k) out: compose -> LM loop -> decompose, all behind the C-ABI
+        (calib_refine_awk). -> (sse, A (3,3), W (M,4,4), k, iters, trace)"""
+        if int(maxIters) <= 0:
+            raise UnboundLocalError("local variable 'Pt_error' referenced before assignment "
+                                    "(maxIters=0, src/calibrate.py:171)")
+        A = np.ascontiguousarray(A, dtype=np.float64).reshape(3, 3).copy()
+        W = np.ascontiguousarray(np.asarray(W, dtype=np.float64).reshape(-1, 4, 4)).copy()
+        k = np.ascontiguousarray(k, dtype=np.float64).ravel().copy()
+        if W.shape[0] != self.M or k.shape[0] != self.L - 5:
+            raise ValueError(f"Expected {self.M} poses and {self.L - 5} distortion coefficients, "
+                             f"got {W.shape[0]} and {k.shape[0]}")
+        trace = np.zeros((int(maxIters), nat.TRACE_HEADER + self.L))
+        sse = ctypes.c_double(0.0)
+        iters = ctypes.c_int(0)
+        nat.check(self._lib.calib_refine_awk(self._h, nat.dptr(A), nat.dptr(W), nat.dptr(k), int(maxIters),
+                                             float(lamInit), float(lamMin), float(lamMax), float(errMin),
+                                             ctypes.byref(sse), ctypes.byref(iters), nat.dptr(trace)))
+        return sse.value, A, W, k, iters.value, trace[:iters.value]
+
     # stepping form (multi-GPU shards, benchmarks)
     def lmBegin(self, P0, maxIters, lamInit=LAMBDA_INITIAL, lamMin=LAMBDA_MIN, lamMax=LAMBDA_MAX,
                 errMin=PT_ERROR_MIN):
@@ -195,6 +217,10 @@ class RefineEngine:
     def lmRun(self, rounds, checkEvery=0):
         nat.check(self._lib.calib_lm_run(self._h, int(rounds), int(checkEvery)))
 
+    def lmRunSharded(self, rounds, checkEvery=0):
+        """whole rounds with the in-library all-reduce between local and update (every rank calls it)"""
+        nat.check(self._lib.calib_lm_run_sharded(self._h, int(rounds), int(checkEvery)))
+
     # ---- in-library all-reduce (include/calib_lm.h: calib_rccl_*) -------------------------------
     def rcclLoad(self, librcclPath):
         nat.check(self._lib.calib_rccl_load(str(librcclPath).encode()))
@@ -204,9 +230,10 @@ class RefineEngine:
         nat.check(self._lib.calib_rccl_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
         return bytes(buf.raw)
 
-    def rcclInit(self, nranks, rank, uniqueId):
+    def rcclInit(self, nranks, rank, uniqueId, timeoutSeconds=120.0):
         buf = ctypes.create_string_buffer(bytes(uniqueId), 128)
-        nat.check(self._lib.calib_rccl_init(self._h, int(nranks), int(rank), ctypes.cast(buf, ctypes.c_void_p)))
+        nat.check(self._lib.calib_rccl_init_deadline(self._h, int(nranks), int(rank), ctypes.cast(buf, ctypes.c_void_p),
+                                                     float(timeoutSeconds)))
 
     def rcclSelfTest(self, timeoutSeconds=30.0):
         nat.check(self._lib.calib_rccl_selftest(self._h, float(timeoutSeconds)))
@@ -251,6 +278,43 @@ class RefineEngine:
         return ms.value, n.value
 
 
+class ResidentProblem:
+    """One RefineEngine kept alive with its correspondences resident in HBM, reused while the caller keeps
+    asking about the same problem (same offsets and model points; sensor points when they are needed):
+    Calibrator.projectAllPoints / _computeReprojectionError / refineCalibrationParameters and
+    ProjectionJacobian.compute then pay engine creation and the upload once, not per call."""
+
+    def __init__(self, modelId, dtype, device):
+        self.modelId, self.dtype, self.device = modelId, dtype, device
+        self.eng = None
+        self._offs = self._sensor = self._model = None
+        self.uploads = 0
+
+    def get(self, viewOffsets, sensorPoints, modelPoints):
+        offs = np.ascontiguousarray(viewOffsets, dtype=np.int64)
+        same = (self.eng is not None and np.array_equal(offs, self._offs) and np.array_equal(modelPoints, self._model)
+                and (sensorPoints is None or (self._sensor is not None and np.array_equal(sensorPoints, self._sensor))))
+        if not same:
+            if self.eng is None:
+                self.eng = RefineEngine(self.modelId, self.dtype, self.device)
+            self.eng.setProblem(offs, sensorPoints, modelPoints)
+            self._offs, self._sensor, self._model = offs, sensorPoints, modelPoints
+            self.uploads += 1
+        return self.eng
+
+    def close(self):
+        if self.eng is not None:
+            self.eng.close()
+            self.eng = None
+        self._offs = self._sensor = self._model = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def refineHomographies(Hs, viewOffsets, sensorPoints, modelPoints, maxIters=20, device=0):
     """LM polish of every view's homography on the device (src/calibrate.py:60-111).
     Hs (M,3,3) -> (M,3,3) with H[2,2] = 1."""
@@ -264,6 +328,35 @@ def refineHomographies(Hs, viewOffsets, sensorPoints, modelPoints, maxIters=20, 
     nat.check(nat.loadLibrary().calib_refine_homographies(H.shape[0], nat.i64ptr(offs), nat.dptr(s), nat.dptr(m),
                                                           nat.dptr(H), int(maxIters), int(device)))
     return H
+
+
+def composeParameters(modelId, A, W, k, device=0):
+    """(A (3,3), W (M,4,4), k) -> P (L + 6M,): Euler angles (degrees) of every pose on the device
+    (src/calibrate.py:199-229, src/mathutils.py:13-33)."""
+    A = np.ascontiguousarray(A, dtype=np.float64).reshape(3, 3)
+    W = np.ascontiguousarray(np.asarray(W, dtype=np.float64).reshape(-1, 4, 4))
+    k = np.ascontiguousarray(k, dtype=np.float64).ravel()
+    if k.shape[0] != NUM_SHARED[modelId] - 5:
+        raise ValueError(f"Expected {NUM_SHARED[modelId] - 5} distortion coefficients, got {k.shape[0]}")
+    P = np.empty(NUM_SHARED[modelId] + 6 * W.shape[0])
+    nat.requireDevice()
+    nat.check(nat.loadLibrary().calib_compose_params(modelId, W.shape[0], nat.dptr(A), nat.dptr(W), nat.dptr(k),
+                                                     nat.dptr(P), int(device)))
+    return P
+
+
+def decomposeParameters(modelId, P, device=0):
+    """P (L + 6M,) -> (A (3,3), W (M,4,4), k): src/calibrate.py:231-267 with the poses rebuilt on the device."""
+    P = np.ascontiguousarray(np.asarray(P, dtype=np.float64).ravel())
+    L = NUM_SHARED[modelId]
+    if P.shape[0] < L or (P.shape[0] - L) % 6:
+        raise ValueError(f"Expected shape ({L} + 6 M,), got {P.shape}")
+    M = (P.shape[0] - L) // 6
+    A, W, k = np.empty((3, 3)), np.empty((M, 4, 4)), np.empty(L - 5)
+    nat.requireDevice()
+    nat.check(nat.loadLibrary().calib_decompose_params(modelId, M, nat.dptr(P), nat.dptr(A), nat.dptr(W), nat.dptr(k),
+                                                       int(device)))
+    return A, W, k
 
 
 def homographyJacobian(h, modelPoints, device=0):

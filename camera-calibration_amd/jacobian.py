@@ -21,21 +21,14 @@ class ProjectionJacobian:
                                                + distortionModel.getDistortionSymbols())
         self._dtype = dtype
         self._device = device
-
-    def _engineFor(self, allModelPoints):
-        offs, model = engine.packModelPoints(allModelPoints)
-        eng = engine.RefineEngine(self._distortionModel.modelId, self._dtype, self._device)
-        eng.setProblem(offs, None, model)
-        return eng, offs
+        self._resident = engine.ResidentProblem(distortionModel.modelId, dtype, device)
 
     def computeCompact(self, P, allModelPoints):
         """(MN, 2, L+6): per point the rows (du, dv) over [shared L | own view's 6] columns.
         This is everything the dense matrix of compute() holds besides structural zeros."""
-        eng, offs = self._engineFor(allModelPoints)
-        try:
-            return eng.evaluate(np.asarray(P, dtype=np.float64).ravel(), wantJ=True)["Jc"]
-        finally:
-            eng.close()
+        offs, model = engine.packModelPoints(allModelPoints)
+        eng = self._resident.get(offs, None, model)
+        return eng.evaluate(np.asarray(P, dtype=np.float64).ravel(), wantJ=True)["Jc"]
 
     def compute(self, P, allModelPoints):
         """Dense J, (2*MN, L+6M): rows (u_j, v_j) interleaved per point in view order, columns

@@ -18,7 +18,8 @@
  *  - All pointer arguments are caller-owned HOST memory unless the name ends
  *    in _dev. The library owns all device memory of a handle.
  *  - One handle = one GPU = one host thread (one process per GPU; shards of a
- *    multi-GPU job are separate handles in separate processes).
+ *    multi-GPU job are separate handles in separate processes). Every entry point that takes a handle makes
+ *    the handle's device the calling thread's current HIP device (hipSetDevice) and leaves it so.
  *  - Parameter vector P (fp64, length K = L + 6*M), exactly the reference's
  *    (src/calibrate.py:199-229):
  *      P = (alpha, beta, gamma, uc, vc, k[0..|k|),  then per view i:
@@ -111,6 +112,21 @@ int calib_refine(calib_handle_t h, double* P_inout, int max_iters,
                  double lam_init, double lam_min, double lam_max, double err_min,
                  double* out_sse, int* out_iters, double* out_trace);
 
+/* Parameter vector (de)composition behind the boundary: Calibrator._composeParameterVector /
+ * _decomposeParameterVector (src/calibrate.py:199-267). A (3,3) row-major, W (M,4,4) board poses in the
+ * camera frame, k (5 radtan | 4 fisheye) <-> P (L + 6 M). Rotations become Euler angles in DEGREES with the
+ * gimbal-lock branches of rotationMatrixToEuler (src/mathutils.py:13-33) and back through
+ * eulerToRotationMatrix (src/mathutils.py:36-51); one device thread per view. Needs no handle.
+ * calib_refine_awk = compose -> calib_refine -> decompose on the handle's problem: the signature of
+ * Calibrator.refineCalibrationParameters (src/calibrate.py:117) for a C caller. */
+int calib_compose_params(int model, int64_t num_views, const double* A, const double* W, const double* k,
+                         double* P_out, int device_id);
+int calib_decompose_params(int model, int64_t num_views, const double* P, double* A_out, double* W_out,
+                           double* k_out, int device_id);
+int calib_refine_awk(calib_handle_t h, double* A_inout, double* W_inout, double* k_inout, int max_iters,
+                     double lam_init, double lam_min, double lam_max, double err_min,
+                     double* out_sse, int* out_iters, double* out_trace);
+
 /* ---- stepping form of the same loop (multi-GPU shards, benchmarks) ----------------
  * One LM round = calib_lm_local (per-shard kernels, fills the reduce buffer)
  *              -> [all-reduce(sum) of the reduce buffer across shards]
@@ -126,9 +142,14 @@ int calib_lm_reduce_size(calib_handle_t h, int64_t* out_num_doubles);
 int calib_lm_bind_reduce_buffer(calib_handle_t h, void* reduce_dev);
 int calib_lm_local(calib_handle_t h);
 int calib_lm_update(calib_handle_t h);
-/* rounds x (local, update) without a collective (single shard). If check_every > 0 the
- * host reads the device's done flag every check_every rounds and stops early. */
+/* rounds x (local, update) without a collective (single shard) -- also on a handle that owns a
+ * communicator: calib_refine, calib_lm_step_delta and calib_normal_eq, which are built on it, never take part
+ * in a collective. If check_every > 0 the host reads the device's done flag every check_every rounds and
+ * stops early. */
 int calib_lm_run(calib_handle_t h, int rounds, int check_every);
+/* rounds x (local, in-library all-reduce, update): every rank of the communicator must make the same call.
+ * CALIB_E_STATE without calib_rccl_init. */
+int calib_lm_run_sharded(calib_handle_t h, int rounds, int check_every);
 
 /* ---- in-library all-reduce (optional) -------------------------------------------------------------
  * The ONE exchange of the sharded loop can also be issued by the library itself, as ncclAllReduce on
@@ -138,14 +159,19 @@ int calib_lm_run(calib_handle_t h, int rounds, int check_every);
  * resolves ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy / ncclCommAbort.
  *   rank 0: calib_rccl_unique_id(id) -> broadcast the 128 bytes by any means -> every rank:
  *   calib_rccl_init(h, nranks, rank, id)   (collective)  -> calib_rccl_selftest(h, timeout_s)
+ * calib_rccl_init blocks until every rank has joined, for at most 120 s (calib_rccl_init_deadline: a
+ * caller-chosen limit); past the deadline it returns CALIB_E_HIP and the handle has no communicator.
  * The self-test all-reduces a rank-dependent vector and checks the sums, polling the stream against the
- * deadline; on a wrong answer or a timeout it aborts the communicator and returns CALIB_E_HIP, and the
- * caller falls back to its own all-reduce (calib_lm_bind_reduce_buffer). After a successful
- * calib_rccl_init, calib_lm_run all-reduces between calib_lm_local and calib_lm_update by itself;
- * calib_lm_allreduce is that step alone, for callers that drive the three steps themselves. */
+ * deadline; on a wrong answer or a timeout it ABORTS the communicator (ncclCommAbort) and returns
+ * CALIB_E_HIP, and the caller falls back to its own all-reduce (calib_lm_bind_reduce_buffer). The collective is
+ * never implicit: calib_lm_run_sharded runs whole rounds (local, all-reduce, update) and calib_lm_allreduce is
+ * that step alone for callers that drive the three steps themselves; calib_lm_run and everything built on it
+ * stay single-shard. Exercised with one rank per process on one GPU (tests/test_gpu_multiproc.py); more than
+ * one GPU has not been available to this build. */
 int calib_rccl_load(const char* librccl_path);
 int calib_rccl_unique_id(void* out_id128);
 int calib_rccl_init(calib_handle_t h, int nranks, int rank, const void* id128);
+int calib_rccl_init_deadline(calib_handle_t h, int nranks, int rank, const void* id128, double timeout_s);
 int calib_rccl_selftest(calib_handle_t h, double timeout_s);
 int calib_rccl_shutdown(calib_handle_t h);
 int calib_lm_allreduce(calib_handle_t h);

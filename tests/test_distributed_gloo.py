@@ -31,6 +31,25 @@ def test_partition_views_balanced_and_contiguous():
     # uniform views split evenly
     offs = np.arange(0, 54 * 1001, 54)
     assert [b - a for a, b in distributed.partitionViews(offs, 8)] == [125] * 8
+    # skewed sizes: with at least as many views as ranks nobody is left without a view
+    for offs in ([0, 1000, 1001, 1002], [0, 1, 2, 1000], [0, 5, 2000, 2001, 2002, 2003]):
+        for world in range(1, len(offs)):
+            parts = distributed.partitionViews(np.array(offs), world)
+            assert all(b > a for a, b in parts), (offs, world, parts)
+            assert parts[0][0] == 0 and parts[-1][1] == len(offs) - 1
+    # fewer views than ranks: the surplus ranks own nothing
+    parts = distributed.partitionViews(np.array([0, 10, 20]), 4)
+    assert sum(b - a for a, b in parts) == 2 and all(b >= a for a, b in parts)
+
+
+def test_validate_global_problem():
+    distributed.validateGlobalProblem(np.array([0, 3, 9]))
+    with pytest.raises(np.linalg.LinAlgError):
+        distributed.validateGlobalProblem(np.array([0, 3, 3, 9]))          # a view without points
+    with pytest.raises(ValueError):
+        distributed.validateGlobalProblem(np.array([0]))
+    with pytest.raises(ValueError):
+        distributed.validateGlobalProblem(np.array([0, 5, 4]))
 
 
 def test_shard_problem_slices():
@@ -135,3 +154,63 @@ def test_refine_distributed_returns_global_result(tmp_path):
     A, W, k = orc.decomposeParameterVector(outs[0]["P"], orc.RADTAN)
     assert np.abs(A - g["Afinal"]).max() < 1e-9 and np.abs(k - g["kfinal"]).max() < 1e-9
     assert np.abs(W - g["Wfinal"]).max() < 1e-8
+
+
+def _workerEdge(rank, world, port, case, outDir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = loadGolden("g2_config1_radtan.npz")
+        offs, s, m, P0 = g["viewOffsets"], g["sensorPoints"], g["modelPoints"], g["P0"]
+        L = 10
+
+        def allReduceFactory(eng):
+            buf = torch.from_numpy(eng.red)
+            return lambda: dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+
+        def factory(o, ss, mm):
+            if case == "rank1_fails" and rank == 1:
+                raise ValueError("this rank cannot build its shard")
+            return OracleShardEngine(orc.RADTAN, o, ss, mm)
+
+        if case in ("more_ranks_than_views", "rank1_fails"):
+            nv = 3                                   # world = 4 > 3 views: one rank owns nothing
+            n = int(offs[nv])
+            args = (np.concatenate((P0[:L], P0[L:L + 6 * nv])), offs[:nv + 1], s[:n], m[:n])
+        else:                                        # "empty_view": every rank must raise before any collective
+            o2 = np.concatenate((offs[:4], offs[3:]))     # view 3 duplicated as an empty view
+            args = (np.concatenate((P0[:L + 18], np.zeros(6), P0[L + 18:])), o2, s, m)
+        out = {"error": ""}
+        try:
+            sse, P, iters, trace = distributed.refineDistributed("radtan", *args, 30, engineFactory=factory,
+                                                                 allReduceFactory=allReduceFactory)
+            out.update(sse=sse, P=P, iters=iters)
+        except Exception as e:      # noqa: BLE001
+            out["error"] = type(e).__name__
+        np.savez(os.path.join(outDir, f"edge{rank}.npz"), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["more_ranks_than_views", "empty_view", "rank1_fails"])
+def test_refine_distributed_edge_cases(tmp_path, case):
+    """Ranks without views follow along; a problem a single engine would reject, or a rank that cannot set
+    itself up, makes EVERY rank raise instead of leaving the others inside the per-round all-reduce."""
+    world = 4
+    mp.spawn(_workerEdge, args=(world, _freePort(), case, str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(os.path.join(tmp_path, f"edge{r}.npz")) for r in range(world)]
+    errs = [str(o["error"]) for o in outs]
+    if case == "more_ranks_than_views":
+        assert errs == [""] * world
+        g = loadGolden("g2_config1_radtan.npz")
+        offs, s, m, P0 = g["viewOffsets"], g["sensorPoints"], g["modelPoints"], g["P0"]
+        n = int(offs[3])
+        sseRef, Pref, _ = orc.refineSchur(orc.RADTAN, np.concatenate((P0[:10], P0[10:28])), offs[:4], s[:n], m[:n], 30)
+        for o in outs:
+            assert np.array_equal(o["P"], outs[0]["P"]) and int(o["iters"]) == int(outs[0]["iters"])
+        assert np.abs(outs[0]["P"] - Pref).max() < 1e-6 * max(1.0, np.abs(Pref).max())
+    elif case == "empty_view":
+        assert errs == ["LinAlgError"] * world
+    else:
+        assert errs[1] == "ValueError" and all(e == "RuntimeError" for i, e in enumerate(errs) if i != 1)

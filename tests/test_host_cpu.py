@@ -45,18 +45,17 @@ def test_pose_helpers_vs_reference_known_answers():
     assert np.abs(np.array(mu.rotationMatrixToEuler(g["R"][3])) - g["eulerBack"][3]).max() < 1e-12
 
 
-def test_compose_decompose_roundtrip_vs_golden():
-    # tests/test_calibrate.py:63-78
+def test_compose_decompose_need_the_device():
+    # the Euler (de)composition of the parameter vector runs behind the C-ABI (calib_compose_params /
+    # calib_decompose_params); its parity test is tests/test_gpu_parity.py::test_compose_decompose_on_device
+    if nat.deviceCount() > 0:
+        pytest.skip("a GPU is visible")
     g = loadGolden("g3_unittest15.npz")
     cal = cca.Calibrator(cca.RadialTangentialModel())
-    P = cal._composeParameterVector(g["Atrue"], list(g["Wtrue"]), tuple(g["ktrue"]))
-    assert P.shape == (6 * 15 + 10, 1)
-    assert np.abs(P.ravel() - g["Ptrue"]).max() < 1e-12
-    A, W, k = cal._decomposeParameterVector(P)
-    assert np.allclose(A, g["Atrue"], atol=1e-9)
-    assert np.allclose(np.array(W), g["Wtrue"], atol=1e-9)
-    assert np.allclose(k, g["ktrue"], atol=1e-9)
-    assert len(W) == 15 and W[0].shape == (4, 4)
+    with pytest.raises(nat.CalibNativeError):
+        cal._composeParameterVector(g["Atrue"], list(g["Wtrue"]), tuple(g["ktrue"]))
+    with pytest.raises(nat.CalibNativeError):
+        cal._decomposeParameterVector(g["Ptrue"])
 
 
 def test_pack_detections_and_sensor_points():
@@ -121,3 +120,24 @@ def test_detections_json_roundtrip(tmp_path):
     assert len(back) == len(dets)
     for (s0, m0), (s1, m1) in zip(dets, back):
         assert np.array_equal(s0, s1) and np.array_equal(m0, m1)
+
+
+def test_mathutils_helpers_vs_reference_known_answers():
+    """exp / skew / unskew / stack / unstack / project / projectStandard (src/mathutils.py:59-117,149-192;
+    call shapes of tests/test_mathutils.py:91-152) against outputs of the reference (golden g8)"""
+    g = loadGolden("g8_surface.npz")
+    for w, R, K, u in zip(g["exp_w"], g["exp_R"], g["skew"], g["unskew"]):
+        assert np.array_equal(mu.skew(mu.col(w)), K)
+        assert np.array_equal(mu.unskew(K), u)
+        assert np.abs(mu.exp(mu.skew(mu.col(w))) - R).max() < 1e-15
+    with pytest.raises(ValueError):
+        mu.skew(np.zeros((3, 2)))            # validateShape, as in the reference
+    with pytest.raises(ValueError):
+        mu.unskew(np.zeros((3, 1)))
+    assert np.array_equal(mu.stack(g["stack_A"]), g["stack_out"])
+    assert np.array_equal(mu.unstack(g["stack_out"]), g["unstack_out"])
+    assert np.abs(mu.project(g["project_A"], g["project_wMc"], g["project_wX"]) - g["project_u"]).max() < 1e-11
+    assert np.abs(mu.projectStandard(g["projectStandard_X"]) - g["projectStandard_x"]).max() < 1e-15
+    with pytest.raises(ValueError):
+        mu.projectStandard(np.zeros((4, 2)))
+    assert mu.radians(180.0) == np.pi and np.array_equal(mu.normalize(np.array([2.0, 4.0])), [0.5, 1.0])

@@ -121,8 +121,11 @@ def test_g4_realistic_final_answer():
     assert np.abs(A - g["Afinal"]).max() < 1e-9 and np.abs(k - g["kfinal"]).max() < 1e-9
 
 
-def test_g5_ragged200_schur_vs_dense_reference_step():
-    g = loadGolden("g5_ragged200.npz")
+@pytest.mark.parametrize("tag", ["g5_ragged200.npz", "g5_ragged1000.npz"])
+def test_g5_ragged_schur_vs_dense_reference_step(tag):
+    """one dense reference step (dense J, J.T @ J, inv) on 200 and on 1000 ragged views -- config 2's scale,
+    where the reference needs ~6 minutes and 10 GB for it -- against the oracle's Schur form"""
+    g = loadGolden(tag)
     offs, s, m, P0 = g["viewOffsets"], g["sensorPoints"], g["modelPoints"], g["P0"]
     d = orc.lmStepSchur(orc.RADTAN, P0, offs, s, m, float(g["lam"]))
     assert np.linalg.norm(d - g["delta"]) / np.linalg.norm(g["delta"]) < 1e-8
