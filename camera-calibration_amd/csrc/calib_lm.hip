@@ -110,6 +110,7 @@ struct calib_handle_s {
 
     // pinned staging of calib_set_problem's uploads (upload_staged)
     bool stage_ready = false;
+    void* stage_pinned = nullptr;
     hipStream_t stage_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     void* stage_buf[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     hipEvent_t stage_ev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
@@ -167,10 +168,11 @@ int rccl_fail(const char* what, int rc) {
 
 // ---- host -> device copies of large caller arrays --------------------------------------------
 // Pageable memory goes over PCIe at ~8 GB/s through hipMemcpy. Here kUploadThreads host threads copy
-// alternating 4 MiB chunks into their own pair of pinned buffers and DMA them from there on their own stream:
-// the host memcpy of one chunk overlaps the DMA of the previous ones.
+// alternating 1 MiB chunks into their own pair of pinned buffers and DMA them from there on the handle's stream:
+// the host memcpy of one chunk overlaps the DMA of the previous ones (measured: 31-40 GB/s). The pinned memory
+// is one 8 MiB allocation per handle -- pinning costs ~0.3 ms per MiB, paid by the handle's first upload.
 constexpr int kUploadThreads = 4;
-constexpr size_t kUploadChunk = (size_t)4 << 20;
+constexpr size_t kUploadChunk = (size_t)1 << 20;
 
 int upload_staged(calib_handle_s* h, void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return CALIB_OK;
@@ -179,10 +181,11 @@ int upload_staged(calib_handle_s* h, void* dst, const void* src, size_t bytes) {
         return CALIB_OK;
     }
     if (!h->stage_ready) {
+        HIP_TRY(hipHostMalloc(&h->stage_pinned, 2 * kUploadThreads * kUploadChunk, hipHostMallocDefault));
         for (int t = 0; t < kUploadThreads; ++t) {
-            HIP_TRY(hipStreamCreateWithFlags(&h->stage_stream[t], hipStreamNonBlocking));
+            h->stage_stream[t] = h->own_stream;       // one DMA queue saturates the link; creating streams costs ms each
             for (int b = 0; b < 2; ++b) {
-                HIP_TRY(hipHostMalloc(&h->stage_buf[t][b], kUploadChunk, hipHostMallocDefault));
+                h->stage_buf[t][b] = static_cast<char*>(h->stage_pinned) + (size_t)(2 * t + b) * kUploadChunk;
                 HIP_TRY(hipEventCreateWithFlags(&h->stage_ev[t][b], hipEventDisableTiming));
             }
         }
@@ -453,10 +456,9 @@ int calib_destroy(calib_handle_t h) {
         for (int t = 0; t < 4; ++t) {
             for (int b = 0; b < 2; ++b) {
                 if (h->stage_ev[t][b]) (void)hipEventDestroy(h->stage_ev[t][b]);
-                if (h->stage_buf[t][b]) (void)hipHostFree(h->stage_buf[t][b]);
             }
-            if (h->stage_stream[t]) (void)hipStreamDestroy(h->stage_stream[t]);
         }
+    if (h->stage_pinned) (void)hipHostFree(h->stage_pinned);
     h->uv.release(); h->XY.release(); h->Z.release(); h->VC.release(); h->J.release();
     h->r.release(); h->y.release(); h->pt_view.release(); h->view_ext.release();
     h->item_n.release(); h->view_item0.release(); h->item_view.release(); h->item_pt0.release(); h->sse_part.release();
@@ -514,6 +516,10 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
     h->M = num_views;
     h->MN = MN;
 
+    const bool timing = std::getenv("CALIB_TIMING") != nullptr;
+    auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tmark = tnow();
+    auto lap = [&](const char* what) { if (timing) { const double t = tnow(); std::fprintf(stderr, "  set_problem %-28s %.3f ms\n", what, t - tmark); tmark = t; } };
     // host side, O(views): compact (non-empty) view list, their point offsets, gram / fused work items.
     // Everything O(points) -- the AoS -> SoA split, the storage-type conversion, the point -> view index --
     // happens on the device from the caller's arrays uploaded as they are (pack_points_kernel).
@@ -596,6 +602,7 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
     const int per = kSchurViewsPerBlock;
     h->schur_blocks = std::max(1, std::min(kMaxSchurBlocks, (h->nv + per - 1) / per));
 
+    lap("host view/item lists");
     const size_t ts = tsize(h);
     HIP_TRY(h->uv.alloc((size_t)MN * 2 * ts));
     HIP_TRY(h->XY.alloc((size_t)MN * 2 * ts));
@@ -613,6 +620,7 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
     HIP_TRY(hipMemsetAsync(h->st_eval.p, 0, sizeof(LMState), h->stream));
     HIP_TRY(h->Peval.alloc((size_t)numParams(h)));
 
+    lap("device allocations");
     auto upload = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
         if (bytes == 0) return hipSuccess;
         return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
@@ -628,8 +636,10 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
         HIP_TRY(xyz_stage.alloc((size_t)MN * 3));
         HIP_TRY(dvoffs.alloc(voffs.size()));
         HIP_TRY(upload(dvoffs.p, voffs.data(), voffs.size() * 8));
+        lap("small uploads + stage alloc");
         int rc = upload_staged(h, xyz_stage.p, model_xyz, (size_t)MN * 24);
         if (rc) return rc;
+        lap("staged upload xyz");
         int uv_mode = 2;
         const double* uv_in = nullptr;
         if (sensor_uv && h->dtype == CALIB_DTYPE_F64) {             // already in the device layout
@@ -643,6 +653,7 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
             uv_in = uv_stage.p;
             uv_mode = 1;
         }
+        lap("staged upload uv");
         const unsigned blocks = (unsigned)((MN + 255) / 256);
         if (h->dtype == CALIB_DTYPE_F64)
             hipLaunchKernelGGL((pack_points_kernel<double>), dim3(blocks), dim3(256), 0, h->stream, xyz_stage.p, uv_in,
@@ -654,6 +665,7 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
                                reinterpret_cast<float*>(h->Z.p), reinterpret_cast<float2*>(h->uv.p), h->pt_view.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(h->stream));                   // the staging buffers go out of scope
+        lap("pack kernel");
     }
     h->has_problem = true;
     return CALIB_OK;

@@ -86,6 +86,7 @@ constexpr int kSchurThreads = 128;  // 8 views (16 lanes each) per workgroup
 constexpr int kMaxSchurBlocks = 1024;
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 // every lane fetches `v` of lane `srcLane` (ds_bpermute: LDS crossbar, no LDS memory)
 __device__ __forceinline__ double2 lane_gather(double2 v, int srcLane) {
@@ -370,6 +371,7 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
     // tile_v[.][3] = sum Jv, i.e. what columns 3 and 4 used to give -- and column 4 the residual
     // (ru, rv): (tile_u + tile_v)[.][4] = J^T r, [4][4] = sum r^2, tile_u[3][4] = sum ru, tile_v[3][4] = sum rv.
     constexpr bool ONES = !RCOL;
+    constexpr bool MF32 = sizeof(T) == 4;                  // fp32 storage: fp32 MFMA per pass, fp64 across passes
     // one slab per wave; after the main loop the same memory holds the wave's two accumulator tiles
     __shared__ __attribute__((aligned(16))) unsigned char smem[WAVES * SLAB * sizeof(T2)];
     if (sel && st->done) return;
@@ -446,12 +448,39 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
                     T2 jv[ROWS / 4];
 #pragma unroll
                     for (int s = 0; s < ROWS / 4; ++s) jv[s] = slab[(4 * s + k) * RS + c];
+                    if constexpr (MF32) {
+                        // fp32 storage: the pass's 32 points are contracted by v_mfma_f32_16x16x4_f32 (twice the fp64
+                        // rate) into fp32 tiles that start at zero, and the tiles are added to the fp64 accumulators:
+                        // fp32 rounding stays confined to sums of 32 products
+                        f4 fu = {0.f, 0.f, 0.f, 0.f}, fv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int s = 0; s < ROWS / 4; ++s) {
+                            fu = __builtin_amdgcn_mfma_f32_16x16x4f32(jv[s].x, jv[s].x, fu, 0, 0, 0);
+                            fv = __builtin_amdgcn_mfma_f32_16x16x4f32(jv[s].y, jv[s].y, fv, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) { acc[reg] += (double)fu[reg]; acc2[reg] += (double)fv[reg]; }
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < ROWS / 4; ++s) {
+                            const double jx = (double)jv[s].x, jy = (double)jv[s].y;
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jx, jx, acc, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc2, 0, 0, 0);
+                        }
+                    }
+                } else if constexpr (MF32) {
+                    // partial pass
+                    f4 fu = {0.f, 0.f, 0.f, 0.f}, fv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int s = 0; s < ROWS / 4; ++s) {
-                        const double jx = (double)jv[s].x, jy = (double)jv[s].y;
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jx, jx, acc, 0, 0, 0);
-                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc2, 0, 0, 0);
+                        if (4 * s >= rows) break;                   // wave-uniform
+                        T2 ja = slab[(4 * s + k) * RS + c];
+                        if (4 * s + k >= rows) { ja.x = T(0); ja.y = T(0); }    // points past the end of the last group
+                        fu = __builtin_amdgcn_mfma_f32_16x16x4f32(ja.x, ja.x, fu, 0, 0, 0);
+                        fv = __builtin_amdgcn_mfma_f32_16x16x4f32(ja.y, ja.y, fv, 0, 0, 0);
                     }
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) { acc[reg] += (double)fu[reg]; acc2[reg] += (double)fv[reg]; }
                 } else {
                     // partial pass: two groups per trip (the second may lie past the end: stale rows, skipped)
 #pragma unroll
@@ -483,8 +512,10 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
     __builtin_amdgcn_wave_barrier();                            // the slab is this wave's own: no workgroup barrier needed yet
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-        TU[(k + 4 * reg) * 16 + c] = acc[reg];
-        TV[(k + 4 * reg) * 16 + c] = acc2[reg];
+        // C/D register -> tile row: fp64 MFMA k + 4 reg, fp32 MFMA (whose tiles the accumulators mirror) 4 k + reg
+        const int row = MF32 ? 4 * k + reg : k + 4 * reg;
+        TU[row * 16 + c] = acc[reg];
+        TV[row * 16 + c] = acc2[reg];
     }
     if (lane == 0) { TU[kEmitZero] = 0.0; TV[kEmitZero] = 0.0; }
     __syncthreads();

@@ -190,6 +190,37 @@ def test_fp32_storage_path():
     eng2.close()
 
 
+def test_fp32_config_at_full_size_vs_fp64_c_oracle():
+    """BASELINE.json configs[3] at its full size -- 100 000 views x 54 points, fp32 storage, the pass's Gram on
+    v_mfma_f32_16x16x4_f32 with fp64 accumulation across passes -- noisy data, against the fp64 C oracle on the same
+    inputs: converged intrinsics within 1e-6 relative (north_star's bar), same lambda schedule on the
+    well-separated early iterations."""
+    from oracle import c_oracle
+    if not c_oracle.available():
+        pytest.skip("C oracle not built")
+    sh = synthetic.makeShard(dict(synthetic.CONFIGS["c4"]), numViews=100000, noiseSigma=0.1)
+    offs, s, m, P0 = sh["viewOffsets"], sh["sensorPoints"], sh["modelPoints"], sh["P0"]
+    assert int(offs[-1]) == 5_400_000
+    eng = cca.RefineEngine("radtan", "f32")
+    eng.setProblem(offs, s, m)
+    sse, P, iters, trace = eng.refine(P0, 30)
+    # normal equations at P0 against the fp64 engine: fp32 evaluation + fp32 MFMA passes stay at the 1e-6 level
+    B32, E32, V32, g32 = eng.normalEquations(P0)
+    eng.close()
+    e64 = cca.RefineEngine("radtan", "f64")
+    e64.setProblem(offs, s, m)
+    B64, E64, V64, g64 = e64.normalEquations(P0)
+    e64.close()
+    assert np.abs(B32 - B64).max() <= 2e-6 * np.abs(B64).max()
+    assert np.abs(V32 - V64).max() <= 2e-5 * np.abs(V64).max()
+    sseO, PO, trO = c_oracle.refine(orc.RADTAN, P0, offs, s, m, 30)
+    assert relIntr(P, PO, 10) < 1e-6, relIntr(P, PO, 10)
+    assert abs(sse - sseO) <= 1e-5 * sseO
+    n = min(4, iters, trO.shape[0])
+    assert np.array_equal(trace[:n, 3], trO[:n, 3]) and np.array_equal(trace[:n, 4], trO[:n, 4])
+    assert np.allclose(trace[:n, 1:3], trO[:n, 1:3], rtol=1e-5)
+
+
 def test_c5_shape_single_shard_sample():
     """configs[4] shard shape (11x8 board, 88 pts/view): 20 000 views, noisy, vs the oracle's
     Schur-form loop on the same inputs (the dense reference form is infeasible at this size)."""
