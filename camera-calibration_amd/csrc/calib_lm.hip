@@ -38,6 +38,25 @@ int fail(int code, const std::string& msg) {
             return fail(CALIB_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));     \
     } while (0)
 
+// after a kernel launch: a launch-time failure is reported with the kernel's name, and the name is remembered so
+// that an ASYNCHRONOUS fault -- seen only at a later synchronisation -- can say what was in flight
+#define LAUNCHED(h, name)                                                                     \
+    do {                                                                                      \
+        if (h) (h)->noteKernel(name);                                                         \
+        hipError_t e__ = hipGetLastError();                                                   \
+        if (e__ != hipSuccess)                                                                \
+            return fail(CALIB_E_HIP, std::string("launch of ") + (name) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+#define SYNC_H(h)                                                                             \
+    do {                                                                                      \
+        hipError_t e__ = hipStreamSynchronize((h)->stream);                                   \
+        if (e__ != hipSuccess)                                                                \
+            return fail(CALIB_E_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e__) + \
+                                     " (kernels enqueued since the last successful synchronisation: " + (h)->recentKernels() + ")"); \
+        (h)->kernels_since_sync.clear();                                                      \
+    } while (0)
+
 #define CHECK_H(h)                                                                            \
     if (!(h)) return fail(CALIB_E_INVALID, "null handle");                                    \
     HIP_TRY(hipSetDevice((h)->device))
@@ -71,6 +90,17 @@ constexpr int kEventPool = 32768;
 }  // namespace
 
 struct calib_handle_s {
+    // names of the kernels enqueued since the last successful synchronisation (distinct, in first-use order)
+    std::vector<const char*> kernels_since_sync;
+    void noteKernel(const char* name) {
+        for (const char* k : kernels_since_sync) if (k == name) return;
+        if (kernels_since_sync.size() < 16) kernels_since_sync.push_back(name);
+    }
+    std::string recentKernels() const {
+        std::string r;
+        for (const char* k : kernels_since_sync) { if (!r.empty()) r += ", "; r += k; }
+        return r.empty() ? "none" : r;
+    }
     int model = 0, dtype = 0, device = 0;
     int L = 10, C = 16;
     hipStream_t own_stream = nullptr;
@@ -227,7 +257,7 @@ int launch_view_setup(calib_handle_s* h, const double* P0, const double* P1, con
     const int blocks = (h->nv + threads - 1) / threads;
     hipLaunchKernelGGL((view_setup_kernel<T>), dim3(blocks), dim3(threads), 0, h->stream, P0, P1, st, sel,
                        h->L, h->view_ext.p, h->nv, reinterpret_cast<T*>(h->VC.p));
-    HIP_TRY(hipGetLastError());
+    LAUNCHED(h, "view_setup_kernel");
     return CALIB_OK;
 }
 
@@ -254,7 +284,7 @@ int launch_jacobian_t(calib_handle_s* h, const double* P0, const double* P1, con
     const unsigned tiles = (unsigned)((p_end - p_begin + kTile - 1) / kTile);
     hipLaunchKernelGGL((jacobian_kernel<MODEL, T>), dim3(tiles), dim3(kTile), lds, h->stream, a);
     prof_end(h, pi);
-    HIP_TRY(hipGetLastError());
+    LAUNCHED(h, "jacobian_kernel");
     return CALIB_OK;
 }
 
@@ -288,7 +318,7 @@ int launch_gram_t(calib_handle_s* h, const LMState* st, int sel, int item0, int 
                        h->G[1].p, h->bpart.p, h->n_bpart);
     prof_end(h, pi);
     h->n_bpart += blocks;                  // the chunk's workgroups append their partials
-    HIP_TRY(hipGetLastError());
+    LAUNCHED(h, "gram_kernel");
     return CALIB_OK;
 }
 
@@ -316,7 +346,7 @@ int launch_fused_t(calib_handle_s* h, const LMState* st, int sel) {
                        h->bpart.p);
     prof_end(h, pi);
     h->n_bpart = blocks;
-    HIP_TRY(hipGetLastError());
+    LAUNCHED(h, "fused_kernel");
     return CALIB_OK;
 }
 
@@ -341,11 +371,11 @@ int launch_schur_reduce(calib_handle_s* h, const LMState* st, double* red) {
         else
             hipLaunchKernelGGL((schur_kernel<9>), grid, dim3(kSchurBlock), 0, h->stream, h->G[0].p,
                                h->G[1].p, st, view_items(h), h->nv, h->bpart.p, h->n_bpart, h->part.p);
-        HIP_TRY(hipGetLastError());
+        LAUNCHED(h, "schur_kernel");
     }
     hipLaunchKernelGGL(reduce_kernel, dim3(2 * VA), dim3(64), 0, h->stream, h->part.p,
                        h->nv > 0 ? h->schur_blocks : 0, VA, st, red);
-    HIP_TRY(hipGetLastError());
+    LAUNCHED(h, "reduce_kernel");
     return CALIB_OK;
 }
 
@@ -361,7 +391,7 @@ int launch_update_backsub_t(calib_handle_s* h) {
     hipLaunchKernelGGL((update_backsub_kernel<L, T>), dim3(blocks), dim3(kSchurThreads), 0, h->stream, h->G[0].p,
                        h->G[1].p, st_cur(h), st_next(h), h->red, view_items(h), h->view_ext.p, h->nv,
                        h->P[0].p, h->P[1].p, h->trace.p, reinterpret_cast<T*>(h->VC.p));
-    HIP_TRY(hipGetLastError());
+    LAUNCHED(h, "update_backsub_kernel");
     return CALIB_OK;
 }
 
@@ -473,7 +503,7 @@ int calib_destroy(calib_handle_t h) {
 
 int calib_set_stream(calib_handle_t h, void* hip_stream, int use_own) {
     CHECK_H(h);
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    SYNC_H(h);
     h->stream = use_own ? h->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
     return CALIB_OK;
 }
@@ -510,7 +540,7 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
     if (MN > 0 && !model_xyz) return fail(CALIB_E_INVALID, "model_xyz is null");
     if (num_views > 0x7fffffffLL / 8 || MN > (int64_t)1 << 40)
         return fail(CALIB_E_INVALID, "problem too large for one shard");
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    SYNC_H(h);
     h->has_problem = false;
     h->lm_active = false;
     h->M = num_views;
@@ -663,8 +693,8 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
             hipLaunchKernelGGL((pack_points_kernel<float>), dim3(blocks), dim3(256), 0, h->stream, xyz_stage.p, uv_in,
                                uv_mode, dvoffs.p, h->nv, MN, reinterpret_cast<float2*>(h->XY.p),
                                reinterpret_cast<float*>(h->Z.p), reinterpret_cast<float2*>(h->uv.p), h->pt_view.p);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(h->stream));                   // the staging buffers go out of scope
+        LAUNCHED(h, "pack_points_kernel");
+        SYNC_H(h);                   // the staging buffers go out of scope
         lap("pack kernel");
     }
     h->has_problem = true;
@@ -691,8 +721,8 @@ int calib_eval(calib_handle_t h, const double* P, double* out_y, double* out_r, 
     if (rc) return rc;
     hipLaunchKernelGGL(sse_reduce_kernel, dim3(1), dim3(256), 0, h->stream, h->sse_part.p, h->n_tiles,
                        h->red_own.p);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    LAUNCHED(h, "sse_reduce_kernel");
+    SYNC_H(h);
     if (out_sse) HIP_TRY(hipMemcpy(out_sse, h->red_own.p, 8, hipMemcpyDeviceToHost));
 
     auto fetch2 = [&](const void* dev, double* out) -> int {   // (MN,2) of T -> double
@@ -736,7 +766,7 @@ int calib_lm_reduce_size(calib_handle_t h, int64_t* out_num_doubles) {
 
 int calib_lm_bind_reduce_buffer(calib_handle_t h, void* reduce_dev) {
     CHECK_H(h);
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    SYNC_H(h);
     HIP_TRY(h->red_own.alloc((size_t)reduceSize(h->L)));
     h->red = reduce_dev ? reinterpret_cast<double*>(reduce_dev) : h->red_own.p;
     return CALIB_OK;
@@ -780,7 +810,7 @@ int calib_lm_begin(calib_handle_t h, const double* P0, int max_iters, double lam
     s.max_iters = max_iters;
     HIP_TRY(hipMemsetAsync(h->st.p, 0, 2 * sizeof(LMState), h->stream));
     HIP_TRY(hipMemcpyAsync(h->st.p, &s, sizeof(s), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));     // s and P0 are host stack / caller memory
+    SYNC_H(h);     // s and P0 are host stack / caller memory
     h->lm_active = true;
     h->lm_max_iters = max_iters;
     h->rounds_enqueued = 0;
@@ -824,7 +854,7 @@ int calib_lm_done(calib_handle_t h, int* out_done) {
     if (!h->lm_active || !out_done) return fail(CALIB_E_STATE, "no LM run active");
     LMState s;
     HIP_TRY(hipMemcpyAsync(&s, st_cur(h), sizeof(s), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    SYNC_H(h);
     *out_done = s.done;
     return CALIB_OK;
 }
@@ -837,7 +867,7 @@ int calib_lm_peek_trace(calib_handle_t h, int iter, double* out_row, int* out_it
     const size_t w = (size_t)(CALIB_TRACE_HEADER + h->L);
     HIP_TRY(hipMemcpyAsync(&s, st_cur(h), sizeof(s), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipMemcpyAsync(out_row, h->trace.p + (size_t)iter * w, w * 8, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    SYNC_H(h);
     *out_iters = s.iters;
     return CALIB_OK;
 }
@@ -1005,7 +1035,7 @@ int calib_lm_allreduce(calib_handle_t h) {
 int calib_lm_end(calib_handle_t h, double* P_out, double* out_sse, int* out_iters, double* out_trace) {
     CHECK_H(h);
     if (!h->lm_active) return fail(CALIB_E_STATE, "no LM run active");
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    SYNC_H(h);
     LMState s;
     HIP_TRY(hipMemcpy(&s, st_cur(h), sizeof(s), hipMemcpyDeviceToHost));
     h->lm_active = false;
@@ -1037,7 +1067,7 @@ int calib_lm_step_delta(calib_handle_t h, const double* P, double lambda, double
     if (rc) return rc;
     rc = calib_lm_run(h, 1, 0);     // bootstrap round: evaluates P, solves, writes P + delta
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    SYNC_H(h);
     LMState s;
     HIP_TRY(hipMemcpy(&s, st_cur(h), sizeof(s), hipMemcpyDeviceToHost));
     h->lm_active = false;
@@ -1058,7 +1088,7 @@ int calib_normal_eq(calib_handle_t h, const double* P, double* out_B, double* ou
     if (rc) return rc;
     rc = calib_lm_local(h);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    SYNC_H(h);
     h->lm_active = false;
     const int L = h->L;
     std::vector<double> red((size_t)reduceSize(L));
@@ -1221,7 +1251,7 @@ int calib_homography_jacobian(int64_t n, const double* h9, const double* model_x
     HIP_TRY(hipMemcpy(dh.p, h9, 72, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dx.p, model_xyz, (size_t)n * 24, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(homography_jacobian_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dh.p, dx.p, n, dJ.p);
-    HIP_TRY(hipGetLastError());
+    LAUNCHED(static_cast<calib_handle_s*>(nullptr), "homography_jacobian_kernel");
     HIP_TRY(hipMemcpy(out_J, dJ.p, (size_t)n * 18 * 8, hipMemcpyDeviceToHost));
     return CALIB_OK;
 }
@@ -1331,7 +1361,7 @@ int calib_compose_params(int model, int64_t num_views, const double* A, const do
     HIP_TRY(dP.alloc((size_t)L + 6 * (size_t)num_views));
     HIP_TRY(hipMemcpy(dW.p, W, (size_t)num_views * 128, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(compose_views_kernel, dim3((unsigned)((num_views + 255) / 256)), dim3(256), 0, 0, dW.p, num_views, L, dP.p);
-    HIP_TRY(hipGetLastError());
+    LAUNCHED(static_cast<calib_handle_s*>(nullptr), "compose_views_kernel");
     HIP_TRY(hipMemcpy(P_out + L, dP.p + L, (size_t)num_views * 48, hipMemcpyDeviceToHost));
     return CALIB_OK;
 }
@@ -1354,7 +1384,7 @@ int calib_decompose_params(int model, int64_t num_views, const double* P, double
     HIP_TRY(dP.alloc((size_t)L + 6 * (size_t)num_views));
     HIP_TRY(hipMemcpy(dP.p, P, ((size_t)L + 6 * (size_t)num_views) * 8, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(decompose_views_kernel, dim3((unsigned)((num_views + 255) / 256)), dim3(256), 0, 0, dP.p, num_views, L, dW.p);
-    HIP_TRY(hipGetLastError());
+    LAUNCHED(static_cast<calib_handle_s*>(nullptr), "decompose_views_kernel");
     HIP_TRY(hipMemcpy(W_out, dW.p, (size_t)num_views * 128, hipMemcpyDeviceToHost));
     return CALIB_OK;
 }
@@ -1376,7 +1406,7 @@ int calib_refine_awk(calib_handle_t h, double* A_inout, double* W_inout, double*
 
 int calib_profile_enable(calib_handle_t h, int on) {
     CHECK_H(h);
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    SYNC_H(h);
     if (on && h->ev.empty()) {
         h->ev.resize(kEventPool);
         h->ev_kind.assign(kEventPool / 2, 0);
@@ -1392,7 +1422,7 @@ int calib_profile_enable(calib_handle_t h, int on) {
 int calib_profile_read(calib_handle_t h, int which, double* out_total_ms, int64_t* out_launches) {
     CHECK_H(h);
     if (!out_total_ms || !out_launches) return fail(CALIB_E_INVALID, "null argument");
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    SYNC_H(h);
     double total = 0.0;
     int64_t count = 0;
     for (size_t i = 0; i + 1 < h->ev_used; i += 2) {

@@ -509,6 +509,35 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
     double* TU = reinterpret_cast<double*>(slab);
     double* TV = TU + kEmitTile;
     double* Gbase = sel ? ((st->cur ^ 1) ? G1 : G0) : G0;
+    if (wpi == 1 && valid) {
+        // One wave per item: the item's record goes to HBM straight from the accumulators (lane (k, c) holds rows
+        // k + 4 reg -- 4 k + reg behind the fp32 MFMA -- of column c; 16 lanes store 128 contiguous bytes): rows
+        // L..L+5 of J^T J, then J^T r and sum r^2 from the residual's row. No table, no LDS, nothing to wait for.
+        constexpr int L = C - 6, RESROW = RCOL ? 15 : 4;
+        double* G = Gbase + (int64_t)item * kGStride;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = MF32 ? 4 * k + reg : k + 4 * reg;
+            double val = acc[reg] + acc2[reg];
+            if (ONES) {
+                // radtan: the u-tile's / v-tile's column 3 is the true column 3 / 4 (sum Ju / sum Jv, see above)
+                const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(acc2[reg]), 0x111, 0xf, 0xf, false);
+                const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(acc2[reg]), 0x111, 0xf, 0xf, false);
+                const double fromLeft = __hiloint2double(hi, lo);       // row_shr:1: lane c <- lane c - 1
+                val = c == 3 ? acc[reg] : (c == 4 ? fromLeft : val);
+            }
+            if (row >= L && row < L + 6) {
+                G[kGRows + (row - L) * 16 + c] = (RCOL && c == 15) ? 0.0 : val;
+            } else if (row == RESROW) {
+                if (RCOL) {
+                    G[c == 15 ? kGSse : kGg + c] = val;
+                } else {
+                    G[kGg + c] = val;
+                    if (c == 4) G[kGSse] = acc[reg] + acc2[reg];
+                }
+            }
+        }
+    }
     __builtin_amdgcn_wave_barrier();                            // the slab is this wave's own: no workgroup barrier needed yet
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
@@ -530,7 +559,7 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
         }
         part[(int64_t)blockIdx.x * kPartStride + threadIdx.x] = o;
     }
-    if (sub != 0 || !valid) return;                             // the item's first wave assembles the record
+    if (wpi == 1 || sub != 0 || !valid) return;                 // items split over waves: the first one assembles the record
     double* G = Gbase + (int64_t)item * kGStride;
     {
         const int i0 = 2 * lane;                                // kGStride = 128: one pass
