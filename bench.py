@@ -294,6 +294,11 @@ def main():
     gramMs, gramN = eng.profileRead(1)
     fusedMs, fusedN = eng.profileRead(2)
     eng.profileEnable(False)
+    # the same upload once more: what a caller pays per calib_set_problem once the handle's pinned staging exists
+    # (the first call above also pays for pinning 8 MiB and the first use of the packing kernel)
+    t0 = time.perf_counter()
+    eng.setProblem(shard["viewOffsets"], shard["sensorPoints"], shard["modelPoints"])
+    tUpload2 = time.perf_counter() - t0
     sse, P = state["sse"], state["P"]
     iters = state["iters"] - itersBefore
     trace = np.vstack(state["trace"]) if state["trace"] else np.zeros((0, 5 + eng.L))
@@ -420,8 +425,8 @@ def main():
                            "error); parity with the reference is asserted on noise-free data in tests/",
                    "max_rel_err_intrinsics_vs_truth": float(np.max(np.abs(P[:L] - shard["Ptrue"][:L])
                                                                    / np.maximum(np.abs(shard["Ptrue"][:L]), 1.0)))},
-            "setup_s": {"generate": tGen, "pack_upload": tUpload,
-                        "pack_upload_GBps": (MNlocal * 40 / tUpload / 1e9) if tUpload > 0 else None,
+            "setup_s": {"generate": tGen, "pack_upload": tUpload, "pack_upload_second_call": tUpload2,
+                        "pack_upload_second_call_GBps": (MNlocal * 40 / tUpload2 / 1e9) if tUpload2 > 0 else None,
                         "clock_spinup_300_untimed_iterations": tSpin},
         }
         if iters != total:

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""profiles/pmc_fused.json (what bench.py quotes as measured counters, with their source) and
+profiles/<round>_<workload>_pmc.json from the counter passes of tools/pmc_pass.sh:
+
+    python tools/make_pmc_fused.py --round r02 --workload c3 --tag c3 --batches 40000 --model fisheye
+
+--batches = 64-lane batches one fused launch evaluates (views x ceil(points per view / 64)).
+Counters are the mean over the dispatches of a kernel; FETCH_SIZE / WRITE_SIZE come in KiB, and on gfx950
+FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read, so it is doubled (MI355X_MICROARCH.md, HBM)."""
+import argparse, csv, glob, json, os, subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(n):
+    return n.replace("void ", "").replace("calib::", "").split("(")[0].split("<")[0]
+
+
+def collect(tag):
+    acc = {}
+    for f in sorted(glob.glob(os.path.join(ROOT, f"gpurun_out/pmc_{tag}_*/**/*counter_collection.csv"), recursive=True)):
+        per = {}
+        for r in csv.DictReader(open(f)):
+            key = (short(r["Kernel_Name"]), r["Counter_Name"], r["Dispatch_Id"])
+            per[key] = per.get(key, 0.0) + float(r["Counter_Value"])
+        for (k, c, _), v in per.items():
+            acc.setdefault(k, {}).setdefault(c, []).append(v)
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items() if not k.startswith("__amd")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--round", default="r02")
+    ap.add_argument("--workload", required=True)
+    ap.add_argument("--tag", required=True)
+    ap.add_argument("--batches", type=int, required=True)
+    ap.add_argument("--model", required=True)
+    a = ap.parse_args()
+    k = collect(a.tag)
+    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    out = os.path.join(ROOT, "profiles", f"{a.round}_{a.workload}_pmc.json")
+    json.dump({"commit": commit, "command": f"tools/pmc_pass.sh {a.tag} (bench.py --steps 10, workload {a.workload})",
+               "mean_per_dispatch": k}, open(out, "w"), indent=1, sort_keys=True)
+    fused = k.get("fused_kernel", {})
+    jac = k.get("jacobian_kernel", {})
+    f64 = 64.0 * (2 * fused.get("SQ_INSTS_VALU_FMA_F64", 0) + fused.get("SQ_INSTS_VALU_MUL_F64", 0)
+                  + fused.get("SQ_INSTS_VALU_ADD_F64", 0) + fused.get("SQ_INSTS_VALU_TRANS_F64", 0)) / a.batches
+    traffic = lambda d: (d.get("FETCH_SIZE", 0) * 1024 * 2 + d.get("WRITE_SIZE", 0) * 1024) if d else None
+    pf = os.path.join(ROOT, "profiles", "pmc_fused.json")
+    d = json.load(open(pf)) if os.path.exists(pf) else {}
+    src = f"profiles/{a.round}_{a.workload}_pmc.json @ {commit}"
+    d[a.workload] = {"valu_f64_flops_per_batch": f64 or None, "fused_hbm_bytes_per_launch": traffic(fused),
+                     "jacobian_hbm_bytes_per_launch": traffic(jac), "source": src,
+                     "valu_instructions_per_batch": (fused.get("SQ_INSTS_VALU", 0) - fused.get("SQ_INSTS_MFMA", 0)) / a.batches}
+    d.setdefault("by_model", {})[a.model] = {"valu_f64_flops_per_batch": f64 or None, "source": src}
+    json.dump(d, open(pf, "w"), indent=1, sort_keys=True)
+    print(json.dumps(d[a.workload]))
+
+
+if __name__ == "__main__":
+    main()
