@@ -115,11 +115,13 @@ def test_refine_matches_reference_result(tag, name, model):
     assert np.abs(P[:L] - g["Pfinal"][:L]).max() < 1e-9, "A, k differ from the reference's result"
     A, W, k = orc.decomposeParameterVector(P, model)
     assert np.abs(W - g["Wfinal"]).max() < 1e-8
-    # well-separated early iterations follow the reference's lambda / error trace
-    n = min(5, iters, ref.shape[0])
-    assert np.array_equal(trace[:n, 3], ref[:n, 2])
-    assert np.allclose(np.minimum(trace[:n, 1], trace[:n, 2]), ref[:n, 1], rtol=1e-6)
-    assert abs(iters - ref.shape[0]) <= 3
+    # the reference's own loop, iteration for iteration: same count, same lambda sequence (every accept / reject
+    # decision), same printed error while it is above the noise floor of the sums
+    assert iters == ref.shape[0]
+    assert np.array_equal(trace[:, 3], ref[:, 2])
+    err = np.minimum(trace[:, 1], trace[:, 2])
+    sep = ref[:, 1] > 1e-13
+    assert np.allclose(err[sep], ref[sep, 1], rtol=1e-6)
     eng.close()
 
 
