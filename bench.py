@@ -28,6 +28,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_MATRIX_PEAK_TFLOPS = 78.6  # public MI355X sheet; fp64 MFMA = fp64 vector rate
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 at the fp32 vector rate
 # fp64 VALU flops the fused kernel executes per 64-point wave batch (all 64 lanes counted) and its HBM traffic
 # are MEASURED quantities of a particular build: rocprofv3 --pmc passes (tools/pmc_pass.sh) summarised into
 # profiles/pmc_fused.json by tools/pmc_summary.py together with the commit they were taken at. bench.py quotes
@@ -372,14 +373,18 @@ def main():
             valuFlops = valuPerBatch * batches if (valuPerBatch and f64) else 0.0
             valuUseful = valuPerBatch * fusedPts / 64.0 if (valuPerBatch and f64) else 0.0
             tf = (mfmaFlops + valuFlops) / (fusedAvgMs * 1e-3) / 1e12
-            mainRoof = {"kernel": "fused_kernel (jacobian blocks + v_mfma_f64_16x16x4_f64 J^T J, J on-chip)",
-                        "bound": "mfma", "achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": tf / FP64_MATRIX_PEAK_TFLOPS,
-                        "useful_frac": (mfmaFlops + valuUseful) / (fusedAvgMs * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+            # fp32 storage (configs[3]): the Gram runs on v_mfma_f32_16x16x4_f32, priced against the fp32 matrix peak;
+            # its fp32 VALU flops are not in profiles/pmc_fused.json, so `achieved` counts the matrix flops only
+            peak = FP64_MATRIX_PEAK_TFLOPS if f64 else FP32_MATRIX_PEAK_TFLOPS
+            mainRoof = {"kernel": "fused_kernel (jacobian blocks + " + ("v_mfma_f64_16x16x4_f64" if f64 else "v_mfma_f32_16x16x4_f32")
+                                  + " J^T J, J on-chip)",
+                        "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
+                        "frac": tf / peak,
+                        "useful_frac": (mfmaFlops + valuUseful) / (fusedAvgMs * 1e-3) / 1e12 / peak,
                         "traffic": fusedTraffic, "traffic_source": pmcSource if fusedTraffic else None,
                         "mfma_flops_per_launch": mfmaFlops, "valu_fp64_flops_per_launch": valuFlops,
                         "valu_flops_source": pmcSource if valuPerBatch else "none: profiles/pmc_fused.json has no entry",
-                        "mfma_only_frac": mfmaFlops / (fusedAvgMs * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+                        "mfma_only_frac": mfmaFlops / (fusedAvgMs * 1e-3) / 1e12 / peak,
                         "points_per_launch": fusedPts,
                         "algorithmic_hbm_bytes_per_launch": 5 * w * fusedPts,
                         "avg_launch_ms": fusedAvgMs, "launches_timed": fusedN,
