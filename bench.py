@@ -128,12 +128,13 @@ def main():
     ap.add_argument("--views", type=int, default=None, help="views per GPU (default: the config's)")
     ap.add_argument("--noise", type=float, default=0.1, help="sensor noise sigma in px")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--allreduce", choices=["auto", "torch", "direct"], default="auto",
-                    help="the one exchange per LM step at N > 1: 'auto' (default) = ncclAllReduce issued by the library on "
-                         "its own stream when its start-up self-test (a checked all-reduce against a deadline) passes on "
-                         "EVERY rank, else torch.distributed.all_reduce; 'torch' / 'direct' force one of them. At world "
-                         "size 1 the in-library path is 7 us per round faster (no hand-off to the process group's stream); "
-                         "it has been exercised with one rank per process only")
+    ap.add_argument("--allreduce", choices=["auto", "peer", "direct", "torch"], default="auto",
+                    help="the one exchange per LM step at N > 1. 'peer': the reduce kernel itself sums over the ranks, "
+                         "point-to-point over xGMI through IPC-mapped slot memory (no collective launch); 'direct': "
+                         "ncclAllReduce issued by the library on its own stream; 'torch': torch.distributed.all_reduce on "
+                         "the bound buffer. 'auto' (default) takes the first of these whose start-up self-test (a checked "
+                         "exchange against a deadline) passes on EVERY rank. peer and direct have been exercised with "
+                         "several processes on one GPU only")
     ap.add_argument("--lm-mode", default="fused", choices=["fused", "two_kernel"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
@@ -209,14 +210,21 @@ def main():
     allReduceKind = None
     if dist is not None:
         allReduce = None
-        if args.allreduce != "torch" and args.backend == "nccl":
+        if args.allreduce in ("auto", "peer") and world > 1:
+            allReduce = distributed.peerExchange(eng)
+            if allReduce is None and args.allreduce == "peer":
+                sys.exit("bench.py --allreduce peer: the peer exchange could not be set up")
+            if allReduce is not None:
+                allReduceKind = "summed inside the reduce kernel, point-to-point over xGMI (IPC-mapped slot memory)"
+        if allReduce is None and args.allreduce in ("auto", "direct") and args.backend == "nccl":
             allReduce = distributed.directAllReduce(eng)
             if allReduce is None and args.allreduce == "direct":
                 sys.exit("bench.py --allreduce direct: the in-library all-reduce could not be set up")
-        allReduceKind = "ncclAllReduce issued by the library on its own stream" if allReduce is not None \
-            else "torch.distributed.all_reduce"
+            if allReduce is not None:
+                allReduceKind = "ncclAllReduce issued by the library on its own stream"
         if allReduce is None:
             allReduce = distributed.torchAllReduce(eng, torch.device("cuda", local))
+            allReduceKind = "torch.distributed.all_reduce"
         lm = distributed.ShardedLM(eng, allReduce)
     state = {"P": shard["P0"], "iters": 0, "trace": [], "sse": float("nan")}
 

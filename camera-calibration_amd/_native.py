@@ -74,6 +74,10 @@ SIGNATURES = {
     "calib_rccl_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "calib_rccl_init": (ctypes.c_int, [_h, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "calib_rccl_init_deadline": (ctypes.c_int, [_h, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_double]),
+    "calib_peer_prepare": (ctypes.c_int, [_h, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "calib_peer_connect": (ctypes.c_int, [_h, ctypes.c_void_p, ctypes.c_double]),
+    "calib_peer_selftest": (ctypes.c_int, [_h, ctypes.c_int, ctypes.c_double]),
+    "calib_peer_shutdown": (ctypes.c_int, [_h]),
     "calib_rccl_selftest": (ctypes.c_int, [_h, ctypes.c_double]),
     "calib_rccl_shutdown": (ctypes.c_int, [_h]),
     "calib_lm_allreduce": (ctypes.c_int, [_h]),

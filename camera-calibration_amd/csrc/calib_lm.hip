@@ -134,6 +134,16 @@ struct calib_handle_s {
     void* comm = nullptr;         // RCCL communicator of the in-library all-reduce (calib_rccl_init), or null
     DevBuf<double> rccl_test;     // operand of calib_rccl_selftest: outlives a collective that timed out
     int comm_ranks = 0, comm_rank = 0;
+    // peer exchange over xGMI (calib_peer_*): the reduce kernel sums over the ranks itself
+    void* peer_mem = nullptr;             // this rank's slot memory (uncached / fine-grained device memory)
+    std::vector<void*> peer_open;         // IPC mappings of the other ranks' slot memory
+    DevBuf<unsigned long long*> peer_slots;
+    DevBuf<int> peer_flags;               // [0] a spin timed out, [1] self-test mismatches
+    int peer_world = 0, peer_rank = 0;
+    unsigned peer_epoch = 0;
+    double peer_timeout_s = 60.0;
+    bool peer_connected = false;
+    bool exchange_round = false;          // the round being enqueued belongs to a sharded run
     bool lm_active = false;
     int lm_max_iters = 0;
     int rounds_enqueued = 0;
@@ -361,6 +371,19 @@ int launch_fused(calib_handle_s* h, const LMState* st, int sel) {
 // per-view kernels skip the view -> item indirection when every view is a single item
 const int* view_items(const calib_handle_s* h) { return h->n_items == h->nv ? nullptr : h->view_item0.p; }
 
+// arguments of the next peer exchange: every rank enqueues the same sequence of exchanges, so the epoch
+// counters advance in lockstep
+PeerExchange next_exchange(calib_handle_s* h) {
+    PeerExchange x;
+    x.slots = h->peer_slots.p;
+    x.fault = h->peer_flags.p;
+    x.timeout_ticks = (unsigned long long)(h->peer_timeout_s * 1e8);      // wall_clock64 counts at 100 MHz
+    x.epoch = ++h->peer_epoch;
+    x.world = h->peer_world;
+    x.rank = h->peer_rank;
+    return x;
+}
+
 int launch_schur_reduce(calib_handle_s* h, const LMState* st, double* red) {
     const int VA = variantSize(h->L);
     if (h->nv > 0) {
@@ -374,7 +397,8 @@ int launch_schur_reduce(calib_handle_s* h, const LMState* st, double* red) {
         LAUNCHED(h, "schur_kernel");
     }
     hipLaunchKernelGGL(reduce_kernel, dim3(2 * VA), dim3(64), 0, h->stream, h->part.p,
-                       h->nv > 0 ? h->schur_blocks : 0, VA, st, red);
+                       h->nv > 0 ? h->schur_blocks : 0, VA, st, red,
+                       h->exchange_round ? next_exchange(h) : PeerExchange{nullptr, nullptr, 0, 0, 0, 0});
     LAUNCHED(h, "reduce_kernel");
     return CALIB_OK;
 }
@@ -476,11 +500,37 @@ int calib_create(int model, int dtype, int device_id, calib_handle_t* out_handle
     return CALIB_OK;
 }
 
+namespace {
+// Slot memory exported by handles of THIS process (one process driving several handles / GPUs): HIP IPC
+// cannot open a handle in the process that made it, so calib_peer_connect looks here first.
+struct LocalSlots { hipIpcMemHandle_t ipc; void* mem; int device; };
+std::vector<LocalSlots> g_local_slots;
+std::mutex g_local_slots_mutex;
+
+void peer_release(calib_handle_s* h) {
+    for (void* m : h->peer_open)
+        if (m) (void)hipIpcCloseMemHandle(m);
+    h->peer_open.clear();
+    if (h->peer_mem) {
+        std::lock_guard<std::mutex> lock(g_local_slots_mutex);
+        for (size_t i = 0; i < g_local_slots.size(); ++i)
+            if (g_local_slots[i].mem == h->peer_mem) { g_local_slots.erase(g_local_slots.begin() + (long)i); break; }
+    }
+    if (h->peer_mem) (void)hipFree(h->peer_mem);
+    h->peer_mem = nullptr;
+    h->peer_slots.release();
+    h->peer_flags.release();
+    h->peer_connected = false;
+    h->peer_world = 0;
+}
+}  // namespace
+
 int calib_destroy(calib_handle_t h) {
     if (!h) return CALIB_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     if (h->comm && g_rccl.commDestroy) { (void)g_rccl.commDestroy(h->comm); h->comm = nullptr; }
+    peer_release(h);
     for (auto& e : h->ev) (void)hipEventDestroy(e);
     if (h->stage_ready)
         for (int t = 0; t < 4; ++t) {
@@ -849,6 +899,19 @@ int calib_lm_update(calib_handle_t h) {
     return rc;
 }
 
+namespace {
+// after a synchronisation: did a peer exchange of this handle give up waiting for a rank?
+int peer_fault_check(calib_handle_s* h) {
+    if (!h->peer_connected) return CALIB_OK;
+    int fault = 0;
+    HIP_TRY(hipMemcpy(&fault, h->peer_flags.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (fault)
+        return fail(CALIB_E_HIP, "peer exchange: a rank's contribution did not arrive before the deadline "
+                                 "(the ranks no longer run in lockstep, or a peer died)");
+    return CALIB_OK;
+}
+}  // namespace
+
 int calib_lm_done(calib_handle_t h, int* out_done) {
     CHECK_H(h);
     if (!h->lm_active || !out_done) return fail(CALIB_E_STATE, "no LM run active");
@@ -856,7 +919,7 @@ int calib_lm_done(calib_handle_t h, int* out_done) {
     HIP_TRY(hipMemcpyAsync(&s, st_cur(h), sizeof(s), hipMemcpyDeviceToHost, h->stream));
     SYNC_H(h);
     *out_done = s.done;
-    return CALIB_OK;
+    return peer_fault_check(h);
 }
 
 int calib_lm_peek_trace(calib_handle_t h, int iter, double* out_row, int* out_iters) {
@@ -879,7 +942,8 @@ int lm_run(calib_handle_t h, int rounds, int check_every, bool sharded);
 int calib_lm_run(calib_handle_t h, int rounds, int check_every) { return lm_run(h, rounds, check_every, false); }
 
 int calib_lm_run_sharded(calib_handle_t h, int rounds, int check_every) {
-    if (h && !h->comm) return fail(CALIB_E_STATE, "calib_rccl_init has not been called");
+    if (h && !h->comm && !h->peer_connected)
+        return fail(CALIB_E_STATE, "neither calib_peer_connect nor calib_rccl_init has been called");
     return lm_run(h, rounds, check_every, true);
 }
 
@@ -887,10 +951,13 @@ namespace {
 int lm_run(calib_handle_t h, int rounds, int check_every, bool sharded) {
     CHECK_H(h);
     if (!h->lm_active) return fail(CALIB_E_STATE, "calib_lm_begin has not been called");
+    const bool peers = sharded && h->peer_connected;      // the reduce kernel sums over the ranks itself
     for (int i = 0; i < rounds; ++i) {
+        h->exchange_round = peers;
         int rc = calib_lm_local(h);
+        h->exchange_round = false;
         if (rc) return rc;
-        if (sharded) {
+        if (sharded && !peers) {
             rc = calib_lm_allreduce(h);
             if (rc) return rc;
         }
@@ -1032,6 +1099,123 @@ int calib_lm_allreduce(calib_handle_t h) {
     return CALIB_OK;
 }
 
+// ---- peer exchange over xGMI ----------------------------------------------------------------
+int calib_peer_prepare(calib_handle_t h, int nranks, int rank, void* out_handle64) {
+    CHECK_H(h);
+    static_assert(sizeof(hipIpcMemHandle_t) == CALIB_PEER_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+    if (!out_handle64 || nranks < 1 || nranks > kPeerMaxRanks || rank < 0 || rank >= nranks)
+        return fail(CALIB_E_INVALID, "bad peer exchange arguments (1 <= nranks <= 64, 0 <= rank < nranks)");
+    if (h->peer_mem) return fail(CALIB_E_STATE, "this handle already takes part in a peer exchange");
+    if (h->lm_active) return fail(CALIB_E_STATE, "cannot set up a peer exchange inside an LM run");
+    // Cells are written by other GPUs while this one polls them: the memory must not be held in this
+    // device's L2 (uncached; fine-grained where the runtime has no uncached pool).
+    const size_t bytes = (size_t)nranks * 2 * kPeerStride * 2 * sizeof(unsigned long long);
+    void* mem = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&mem, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipExtMallocWithFlags(&mem, bytes, hipDeviceMallocFinegrained);
+    }
+    if (e != hipSuccess) return fail(CALIB_E_HIP, std::string("peer slot memory: ") + hipGetErrorString(e));
+    h->peer_mem = mem;
+    h->peer_world = nranks;
+    h->peer_rank = rank;
+    auto undo = [&](int code, const std::string& msg) { peer_release(h); return fail(code, msg); };
+    e = hipMemset(mem, 0, bytes);          // epoch 0 is never sent
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return undo(CALIB_E_HIP, std::string("peer slot memory: ") + hipGetErrorString(e));
+    hipIpcMemHandle_t ipc;
+    e = hipIpcGetMemHandle(&ipc, mem);
+    if (e != hipSuccess) return undo(CALIB_E_HIP, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e));
+    std::memcpy(out_handle64, &ipc, sizeof(ipc));
+    {
+        std::lock_guard<std::mutex> lock(g_local_slots_mutex);
+        g_local_slots.push_back(LocalSlots{ipc, mem, h->device});
+    }
+    return CALIB_OK;
+}
+
+int calib_peer_connect(calib_handle_t h, const void* handles, double timeout_s) {
+    CHECK_H(h);
+    if (!handles) return fail(CALIB_E_INVALID, "null argument");
+    if (!h->peer_mem) return fail(CALIB_E_STATE, "calib_peer_prepare has not been called");
+    if (h->peer_connected) return fail(CALIB_E_STATE, "peers are already connected");
+    const int n = h->peer_world;
+    std::vector<unsigned long long*> slots((size_t)n, nullptr);
+    h->peer_open.assign((size_t)n, nullptr);
+    for (int r = 0; r < n; ++r) {
+        if (r == h->peer_rank) { slots[(size_t)r] = static_cast<unsigned long long*>(h->peer_mem); continue; }
+        hipIpcMemHandle_t ipc;
+        std::memcpy(&ipc, static_cast<const char*>(handles) + (size_t)r * sizeof(ipc), sizeof(ipc));
+        void* m = nullptr;
+        hipError_t pe = hipSuccess;
+        {
+            std::lock_guard<std::mutex> lock(g_local_slots_mutex);
+            for (const LocalSlots& ls : g_local_slots)
+                if (std::memcmp(&ls.ipc, &ipc, sizeof(ipc)) == 0) {
+                    if (ls.device != h->device) {
+                        pe = hipDeviceEnablePeerAccess(ls.device, 0);
+                        if (pe == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); pe = hipSuccess; }
+                    }
+                    m = ls.mem;
+                }
+        }
+        if (pe != hipSuccess) {
+            (void)hipGetLastError();
+            for (void*& o : h->peer_open) { if (o) (void)hipIpcCloseMemHandle(o); o = nullptr; }
+            return fail(CALIB_E_HIP, "hipDeviceEnablePeerAccess (device of rank " + std::to_string(r) + "): " + hipGetErrorString(pe));
+        }
+        if (m) { slots[(size_t)r] = static_cast<unsigned long long*>(m); continue; }
+        const hipError_t e = hipIpcOpenMemHandle(&m, ipc, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            for (void*& o : h->peer_open) { if (o) (void)hipIpcCloseMemHandle(o); o = nullptr; }
+            return fail(CALIB_E_HIP, "hipIpcOpenMemHandle (slot memory of rank " + std::to_string(r) + "): " + hipGetErrorString(e));
+        }
+        h->peer_open[(size_t)r] = m;
+        slots[(size_t)r] = static_cast<unsigned long long*>(m);
+    }
+    HIP_TRY(h->peer_slots.alloc((size_t)n));
+    HIP_TRY(h->peer_flags.alloc(2));
+    HIP_TRY(hipMemcpy(h->peer_slots.p, slots.data(), (size_t)n * sizeof(slots[0]), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(h->peer_flags.p, 0, 2 * sizeof(int)));
+    h->peer_timeout_s = timeout_s > 0 ? timeout_s : 60.0;
+    h->peer_epoch = 0;
+    h->peer_connected = true;
+    return CALIB_OK;
+}
+
+int calib_peer_selftest(calib_handle_t h, int rounds, double timeout_s) {
+    CHECK_H(h);
+    if (!h->peer_connected) return fail(CALIB_E_STATE, "calib_peer_connect has not been called");
+    if (rounds < 1) rounds = 1;
+    const double keep = h->peer_timeout_s;
+    h->peer_timeout_s = timeout_s > 0 ? timeout_s : 10.0;       // each spin of the test gives up after this long
+    for (int r = 0; r < rounds; ++r) {
+        hipLaunchKernelGGL(peer_selftest_kernel, dim3(kPeerStride), dim3(64), 0, h->stream, next_exchange(h), r,
+                           h->peer_flags.p + 1);
+        LAUNCHED(h, "peer_selftest_kernel");
+    }
+    h->peer_timeout_s = keep;
+    SYNC_H(h);
+    int flags[2] = {0, 0};
+    HIP_TRY(hipMemcpy(flags, h->peer_flags.p, sizeof(flags), hipMemcpyDeviceToHost));
+    if (flags[0] || flags[1]) {
+        HIP_TRY(hipMemset(h->peer_flags.p, 0, sizeof(flags)));
+        return fail(CALIB_E_HIP, flags[0] ? "peer exchange self-test: a rank's contribution did not arrive in time"
+                                          : "peer exchange self-test: wrong sums (" + std::to_string(flags[1]) + " elements)");
+    }
+    return CALIB_OK;
+}
+
+int calib_peer_shutdown(calib_handle_t h) {
+    CHECK_H(h);
+    if (h->lm_active) return fail(CALIB_E_STATE, "cannot drop the peer exchange inside an LM run");
+    (void)hipStreamSynchronize(h->stream);
+    peer_release(h);
+    return CALIB_OK;
+}
+
 int calib_lm_end(calib_handle_t h, double* P_out, double* out_sse, int* out_iters, double* out_trace) {
     CHECK_H(h);
     if (!h->lm_active) return fail(CALIB_E_STATE, "no LM run active");
@@ -1039,6 +1223,8 @@ int calib_lm_end(calib_handle_t h, double* P_out, double* out_sse, int* out_iter
     LMState s;
     HIP_TRY(hipMemcpy(&s, st_cur(h), sizeof(s), hipMemcpyDeviceToHost));
     h->lm_active = false;
+    const int prc = peer_fault_check(h);
+    if (prc) return prc;
     if (s.error == CALIB_E_SINGULAR)
         return fail(CALIB_E_SINGULAR, "Singular matrix: damped normal equations are not invertible");
     // after the bootstrap round cur points at the current parameters
@@ -1071,6 +1257,8 @@ int calib_lm_step_delta(calib_handle_t h, const double* P, double lambda, double
     LMState s;
     HIP_TRY(hipMemcpy(&s, st_cur(h), sizeof(s), hipMemcpyDeviceToHost));
     h->lm_active = false;
+    const int prc = peer_fault_check(h);
+    if (prc) return prc;
     if (s.error == CALIB_E_SINGULAR)
         return fail(CALIB_E_SINGULAR, "Singular matrix: damped normal equations are not invertible");
     const int64_t K = numParams(h);

@@ -766,12 +766,81 @@ __global__ __launch_bounds__(kSchurBlock) void schur_kernel(const double* __rest
     }
 }
 
+// ---------------------------------------------------------------- peer exchange over xGMI
+// The cross-GPU sum of the reduce buffer, done by reduce_kernel itself: no collective launch, no fence.
+// Every rank owns SLOT MEMORY (uncached / fine-grained device memory, mapped into every peer through HIP IPC)
+// of world x 2 x kPeerStride 16-byte cells; cell (src, parity, i) of rank d's memory holds element i as
+// contributed by rank src in a round of that parity. A cell is two 8-byte words {data half, epoch}: an 8-byte
+// word is never torn, so a reader that sees the round's epoch in a word also sees that word's data (the
+// "LL" idea of the collective libraries) -- the writer needs no release fence and no separate flag. A wave
+// that has summed element i stores it into cell (rank, parity, i) of EVERY rank (lane d writes to rank d,
+// point-to-point over xGMI, its own memory included), then lane s polls cell (s, parity, i) of its own
+// memory until rank s's epoch shows up; the values are added in rank order, so every rank gets bitwise the
+// same sums. Two parities are enough: a rank can only start writing round r + 2 after it has received
+// everybody's round r + 1, which they sent after reading round r.
+// Every spin is bounded by the wall clock (100 MHz): on a timeout the fault word is raised, the element
+// becomes NaN (the step is rejected) and the host reports the fault; the grid always drains.
+constexpr int kPeerStride = 448;       // >= reduceSize(10) = 444 cells per (source, parity)
+constexpr int kPeerMaxRanks = 64;      // one lane per rank
+
+struct PeerExchange {
+    unsigned long long* const* slots;  // [world] rank d's slot memory as mapped on this device (device array)
+    int* fault;
+    unsigned long long timeout_ticks;
+    unsigned epoch;                    // > 0, +1 per exchange; identical on every rank
+    int world, rank;
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// one 16-byte cell, system scope (sc0 sc1: past this device's caches). The hardware may split the access
+// into its two 8-byte words -- each carries its own epoch, so a torn cell is simply not ready yet.
+__device__ __forceinline__ void cell_store(unsigned long long* cell, u32x4 v) {
+    asm volatile("flat_store_dwordx4 %0, %1 sc0 sc1" : : "v"(cell), "v"(v) : "memory");
+}
+__device__ __forceinline__ u32x4 cell_load(const unsigned long long* cell) {
+    u32x4 v;
+    asm volatile("flat_load_dwordx4 %0, %1 sc0 sc1\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" : "=v"(v) : "v"(cell) : "memory");
+    return v;
+}
+
+__device__ __forceinline__ double peer_sum(const PeerExchange& x, int i, double t, int lane) {
+    const unsigned par = x.epoch & 1u;
+    double v = 0.0;
+    if (lane < x.world) {
+        unsigned long long* dst = x.slots[lane] + 2 * ((int64_t)(x.rank * 2 + par) * kPeerStride + i);
+        u32x4 mine;
+        mine.x = (unsigned)__double2loint(t); mine.y = x.epoch;
+        mine.z = (unsigned)__double2hiint(t); mine.w = x.epoch;
+        cell_store(dst, mine);
+        const unsigned long long* src = x.slots[x.rank] + 2 * ((int64_t)(lane * 2 + par) * kPeerStride + i);
+        const long long t0 = wall_clock64();
+        for (;;) {
+            const u32x4 c = cell_load(src);
+            if (c.y == x.epoch && c.w == x.epoch) {
+                v = __hiloint2double((int)c.z, (int)c.x);
+                break;
+            }
+            if ((unsigned long long)(wall_clock64() - t0) > x.timeout_ticks) {
+                __hip_atomic_store(x.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = __builtin_nan("");
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    double acc = 0.0;
+    for (int r = 0; r < x.world; ++r) acc += __shfl(v, r, 64);
+    return acc;
+}
+
 // ---------------------------------------------------------------- reduce
 // One wave per reduce-buffer element: lanes stride over the schur block partials, then a
-// fixed-order shuffle tree. grid = 2 * VA.
+// fixed-order shuffle tree. grid = 2 * VA. With a peer exchange (x.world > 1) the element is then summed
+// over the ranks as well.
 __global__ __launch_bounds__(64) void reduce_kernel(const double* __restrict__ part, int nblocks, int VA,
                                                     const LMState* __restrict__ st,
-                                                    double* __restrict__ red) {
+                                                    double* __restrict__ red, PeerExchange x) {
     if (st->done) return;
     const int i = blockIdx.x, lane = threadIdx.x;
     const int variant = i / VA, idx = i - variant * VA;
@@ -791,7 +860,18 @@ __global__ __launch_bounds__(64) void reduce_kernel(const double* __restrict__ p
     double t = v[0];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if (x.world > 1) t = peer_sum(x, i, __shfl(t, 0, 64), lane);
     if (lane == 0) red[i] = t;
+}
+
+// calib_peer_selftest: rank r contributes (r + 1) * (i + 1) + round to element i; every rank must read
+// back the exact integer sum.
+__global__ __launch_bounds__(64) void peer_selftest_kernel(PeerExchange x, int round, int* __restrict__ mismatches) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const double mine = (double)(x.rank + 1) * (i + 1) + round;
+    const double got = peer_sum(x, i, mine, lane);
+    const double want = 0.5 * x.world * (x.world + 1.0) * (i + 1) + (double)round * x.world;
+    if (lane == 0 && !(got == want)) atomicAdd(mismatches, 1);
 }
 
 // sum of the jacobian kernel's per-tile partials (calib_eval only), one workgroup

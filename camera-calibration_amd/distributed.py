@@ -4,9 +4,11 @@ Rows of J belonging to different views are independent given P, and a view's six
 extrinsics appear only in its own rows (src/jacobian.py:81-83), so each rank keeps a
 contiguous range of views resident in its HBM and eliminates their 6x6 blocks locally.
 What is shared is the L x L Schur system: per LM round every rank contributes its partial
-sums (reduce buffer of calib_lm.h: 444 doubles for L = 10, 364 for L = 9) to ONE sum all-reduce (RCCL over
-xGMI through torch.distributed), after which every rank takes the identical accept/reject
-decision and solves the identical L x L system redundantly. No other data-path collective.
+sums (reduce buffer of calib_lm.h: 444 doubles for L = 10, 364 for L = 9) to ONE sum over the ranks, after
+which every rank takes the identical accept/reject decision and solves the identical L x L system
+redundantly. No other data-path exchange. The sum has three carriers, tried in this order: the engine's
+reduce kernel exchanging its elements point-to-point over xGMI (peerExchange), the library's own
+ncclAllReduce (directAllReduce), torch.distributed.all_reduce on the bound buffer (torchAllReduce).
 
 The driver is generic over the shard engine (RefineEngine on the GPU; tests drive the
 same code with a CPU test double over gloo).
@@ -74,6 +76,9 @@ class ShardedLM:
         self.round()                    # round 0: evaluate P0, first step
 
     def round(self):
+        if getattr(self.allReduce, "inLibrary", False):
+            self.eng.lmRunSharded(1, 0)
+            return
         self.eng.lmLocal()
         self.allReduce()
         self.eng.lmUpdate()
@@ -110,6 +115,63 @@ def torchAllReduce(eng, device):
     return allReduce
 
 
+def _allRanksOk(ok, dev):
+    """MIN over the ranks of a local success flag: every rank takes the same branch."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def peerExchange(eng, timeoutSeconds=60.0, selfTestRounds=64, selfTestTimeout=10.0):
+    """Sum the reduce buffer over the ranks INSIDE the engine's reduce kernel (include/calib_lm.h,
+    calib_peer_*): every rank maps every other rank's slot memory through HIP IPC, stores its elements
+    point-to-point over xGMI and polls its own memory for the others' -- no collective launch per LM round.
+    The 64-byte IPC handles travel over the default process group (any backend); before the exchange is
+    trusted it is run on known values against a deadline.
+    -> the all-reduce callable (inLibrary: whole rounds run from C), or None when any rank could not set it
+    up (the caller then falls back to directAllReduce / torchAllReduce); every rank takes the same branch."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = torch.device("cuda", getattr(eng, "device", torch.cuda.current_device()))
+    mine = None
+    try:
+        mine = eng.peerPrepare(world, rank)
+    except Exception:       # noqa: BLE001 -- agreed on below
+        mine = None
+    handles = [None] * world
+    dist.all_gather_object(handles, mine)
+    ok = all(hd is not None for hd in handles)
+    if ok:
+        try:
+            eng.peerConnect(handles, timeoutSeconds)
+        except Exception:   # noqa: BLE001
+            ok = False
+    if _allRanksOk(ok, dev):
+        try:
+            eng.peerSelfTest(selfTestRounds, selfTestTimeout)
+        except Exception:   # noqa: BLE001
+            ok = False
+        ok = _allRanksOk(ok, dev)
+    else:
+        ok = False
+    if not ok:
+        try:
+            eng.peerShutdown()
+        except Exception:   # noqa: BLE001
+            pass
+        return None
+
+    def allReduce():
+        raise RuntimeError("the peer exchange happens inside lmRunSharded")
+
+    allReduce.inLibrary = True
+    allReduce.kind = "peer"
+    return allReduce
+
+
 def directAllReduce(eng, timeoutSeconds=30.0):
     """Let the engine issue the all-reduce itself (ncclAllReduce on its own stream, RCCL resolved from
     the librccl.so PyTorch ships and has already loaded): no hand-off to the process group's stream,
@@ -124,9 +186,7 @@ def directAllReduce(eng, timeoutSeconds=30.0):
     dev = torch.device("cuda", getattr(eng, "device", torch.cuda.current_device()))      # the ENGINE's device
 
     def allRanksOk(ok):
-        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return bool(t.item())
+        return _allRanksOk(ok, dev)
 
     ok = True
     try:
@@ -161,6 +221,7 @@ def directAllReduce(eng, timeoutSeconds=30.0):
         eng.lmAllReduce()
 
     allReduce.inLibrary = True
+    allReduce.kind = "direct"
     return allReduce
 
 
@@ -213,8 +274,13 @@ def refineDistributed(modelName, P0, viewOffsets, sensorPoints, modelPoints, max
         err = e
     _raiseTogether(dist, torch, err, okDevice)
     if onGpu:
-        # CALIB_ALLREDUCE=direct|auto: the library issues ncclAllReduce itself (self-tested; torch otherwise)
-        if os.environ.get("CALIB_ALLREDUCE", "torch") != "torch" and dist.get_backend() == "nccl":
+        # CALIB_ALLREDUCE = peer | direct | torch | auto (default): the exchange inside the reduce kernel over
+        # xGMI, the library's own ncclAllReduce, torch.distributed.all_reduce; auto tries them in that order.
+        # Each is self-tested and agreed on by all ranks before it is used.
+        want = os.environ.get("CALIB_ALLREDUCE", "auto")
+        if want in ("peer", "auto") and world > 1:
+            allReduce = peerExchange(eng)
+        if allReduce is None and want in ("direct", "auto") and dist.get_backend() == "nccl":
             allReduce = directAllReduce(eng)
         if allReduce is None:
             allReduce = torchAllReduce(eng, torch.device("cuda", eng.device))
@@ -232,6 +298,7 @@ def refineDistributed(modelName, P0, viewOffsets, sensorPoints, modelPoints, max
     lm.round()
     lm.run(maxIters, checkEvery=checkEvery)
     sse, Plocal, iters, trace = lm.end()
+    refineDistributed.lastAllReduce = getattr(allReduce, "kind", "torch")
     # assemble the global parameter vector: shared part is replicated, extrinsics are gathered
     gathered = [None] * world
     dist.all_gather_object(gathered, (parts[rank], Plocal[L:]))

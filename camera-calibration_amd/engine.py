@@ -221,6 +221,25 @@ class RefineEngine:
         """whole rounds with the in-library all-reduce between local and update (every rank calls it)"""
         nat.check(self._lib.calib_lm_run_sharded(self._h, int(rounds), int(checkEvery)))
 
+    # ---- peer exchange over xGMI (include/calib_lm.h: calib_peer_*) ------------------------------
+    def peerPrepare(self, nranks, rank):
+        """-> this rank's 64-byte IPC handle of its slot memory (bytes)."""
+        buf = (ctypes.c_ubyte * 64)()
+        nat.check(self._lib.calib_peer_prepare(self._h, int(nranks), int(rank), ctypes.cast(buf, ctypes.c_void_p)))
+        return bytes(buf)
+
+    def peerConnect(self, handles, timeoutSeconds=60.0):
+        """handles: the ranks' peerPrepare results in rank order."""
+        blob = b"".join(handles)
+        buf = (ctypes.c_ubyte * len(blob)).from_buffer_copy(blob)
+        nat.check(self._lib.calib_peer_connect(self._h, ctypes.cast(buf, ctypes.c_void_p), float(timeoutSeconds)))
+
+    def peerSelfTest(self, rounds=64, timeoutSeconds=10.0):
+        nat.check(self._lib.calib_peer_selftest(self._h, int(rounds), float(timeoutSeconds)))
+
+    def peerShutdown(self):
+        nat.check(self._lib.calib_peer_shutdown(self._h))
+
     # ---- in-library all-reduce (include/calib_lm.h: calib_rccl_*) -------------------------------
     def rcclLoad(self, librcclPath):
         nat.check(self._lib.calib_rccl_load(str(librcclPath).encode()))

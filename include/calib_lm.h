@@ -147,9 +147,34 @@ int calib_lm_update(calib_handle_t h);
  * in a collective. If check_every > 0 the host reads the device's done flag every check_every rounds and
  * stops early. */
 int calib_lm_run(calib_handle_t h, int rounds, int check_every);
-/* rounds x (local, in-library all-reduce, update): every rank of the communicator must make the same call.
- * CALIB_E_STATE without calib_rccl_init. */
+/* rounds x (local, exchange, update) with the exchange done by the library: summed inside the reduce kernel
+ * over xGMI when peers are connected (calib_peer_connect), else an ncclAllReduce (calib_rccl_init). Every rank
+ * must make the same call. CALIB_E_STATE when the handle has neither. */
 int calib_lm_run_sharded(calib_handle_t h, int rounds, int check_every);
+
+/* ---- peer exchange over xGMI (optional; the fastest form of the one exchange) -----------------------
+ * The sum over the ranks happens INSIDE the kernel that finishes a shard's reduce buffer: each wave stores its
+ * element point-to-point into every rank's slot memory and polls its own for the others' (kernels.hpp,
+ * "peer exchange"); no collective is launched, no stream is handed over, and every rank adds in rank order,
+ * so the reduced system -- hence every accept/reject decision -- is bitwise identical everywhere. It replaces
+ * the all-reduce torch.distributed / RCCL would launch per LM round. One process per GPU, ranks on one node:
+ *   every rank: calib_peer_prepare(h, nranks, rank, handle64)       allocates its slot memory, exports it (HIP IPC)
+ *   all-gather the CALIB_PEER_HANDLE_BYTES-byte handles by any means (rank order)
+ *   every rank: calib_peer_connect(h, handles, timeout_s)            maps the peers' slot memory
+ *   every rank: calib_peer_selftest(h, rounds, timeout_s)            exchanges known values, checks the sums
+ * then calib_lm_run_sharded runs whole rounds. A rank that waits longer than timeout_s (<= 0: 60 s) for a
+ * contribution stops waiting: the step is rejected, and calib_lm_done / calib_lm_end (and the self-test)
+ * return CALIB_E_HIP -- the kernels never spin without bound. Handles of one exchange must call
+ * calib_lm_run_sharded in lockstep (same number of rounds; they stop together because the done flag is derived
+ * from the identical sums). calib_lm_run and everything built on it stay single-shard on a connected handle.
+ * calib_peer_shutdown (or calib_destroy) unmaps and frees. nranks <= 64.
+ * Exercised with one rank per process on ONE GPU (tests/test_gpu_multiproc.py); callers should keep the
+ * self-test and fall back to calib_rccl_* / their own all-reduce when it fails on any rank. */
+#define CALIB_PEER_HANDLE_BYTES 64
+int calib_peer_prepare(calib_handle_t h, int nranks, int rank, void* out_handle64);
+int calib_peer_connect(calib_handle_t h, const void* handles, double timeout_s);
+int calib_peer_selftest(calib_handle_t h, int rounds, double timeout_s);
+int calib_peer_shutdown(calib_handle_t h);
 
 /* ---- in-library all-reduce (optional) -------------------------------------------------------------
  * The ONE exchange of the sharded loop can also be issued by the library itself, as ncclAllReduce on

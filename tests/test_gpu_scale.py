@@ -127,6 +127,70 @@ def test_two_shards_in_lockstep_match_one_shard(c3):
         e.close()
 
 
+def test_peer_exchange_two_handles_one_process_bitwise_equal_to_host_sum(c3):
+    """calib_peer_*: two handles of ONE process (slot memory found in the process-local registry instead of
+    through HIP IPC), each on its own stream, run whole rounds from C while their reduce kernels exchange the
+    elements. The sums are formed in rank order, exactly like `bufs[0] + bufs[1]` of the test above, so the
+    run must reproduce that protocol bit for bit."""
+    import torch
+    L, nv, iters = 9, 600, 25
+    offs = c3["viewOffsets"][:nv + 1]
+    n = int(offs[-1])
+    s, m = c3["sensorPoints"][:n] + np.random.default_rng(2).normal(0, 0.1, (n, 2)), c3["modelPoints"][:n]
+    P0 = np.concatenate((c3["P0"][:L], c3["P0"][L:L + 6 * nv]))
+    parts = distributed.partitionViews(offs, 2)
+    shards = [distributed.shardProblem(P0, offs, s, m, L, part) for part in parts]
+
+    def hostSummed():
+        engs, bufs = [], []
+        for Pl, ol, sl, ml in shards:
+            e = cca.RefineEngine("fisheye", "f64")
+            e.setProblem(ol, sl, ml)
+            b = torch.zeros(e.reduceSize(), dtype=torch.float64, device="cuda")
+            e.setStream(torch.cuda.current_stream().cuda_stream)
+            e.bindReduceBuffer(b.data_ptr())
+            e.lmBegin(Pl, iters)
+            engs.append(e); bufs.append(b)
+        for rnd in range(iters + 1):
+            for e in engs:
+                e.lmLocal()
+            total = bufs[0] + bufs[1]
+            bufs[0].copy_(total); bufs[1].copy_(total)
+            for e in engs:
+                e.lmUpdate()
+        outs = [e.lmEnd() for e in engs]
+        for e in engs:
+            e.close()
+        return outs
+
+    def peerSummed():
+        engs = []
+        for Pl, ol, sl, ml in shards:
+            e = cca.RefineEngine("fisheye", "f64")
+            e.setProblem(ol, sl, ml)
+            engs.append(e)
+        handles = [e.peerPrepare(2, r) for r, e in enumerate(engs)]
+        for e in engs:
+            e.peerConnect(handles, 20.0)
+        for (Pl, _, _, _), e in zip(shards, engs):
+            e.lmBegin(Pl, iters)
+        # nothing below waits for the device until both handles have enqueued all their rounds: each reduce
+        # kernel spins (on its own stream) until the other handle's contribution of that round has arrived
+        for e in engs:
+            e.lmRunSharded(iters + 1, 0)
+        outs = [e.lmEnd() for e in engs]
+        for e in engs:
+            e.peerShutdown()
+            e.close()
+        return outs
+
+    ref, got = hostSummed(), peerSummed()
+    for r in range(2):
+        assert got[r][2] == ref[r][2] and got[r][0] == ref[r][0]
+        assert np.array_equal(got[r][1], ref[r][1]) and np.array_equal(got[r][3], ref[r][3])
+    assert np.array_equal(got[0][1][:L], got[1][1][:L])
+
+
 def test_torch_distributed_binding_world_size_1(c3):
     """ShardedLM + torchAllReduce over the nccl (= RCCL) backend with one rank: the engine's kernels
     run on torch's stream and the reduce buffer is a torch tensor."""
