@@ -408,8 +408,19 @@ int launch_schur_reduce(calib_handle_s* h, const LMState* st, double* red) {
 LMState* st_cur(calib_handle_s* h) { return h->st.p + (h->rounds_enqueued & 1); }
 LMState* st_next(calib_handle_s* h) { return h->st.p + ((h->rounds_enqueued + 1) & 1); }
 
+// shards of at most this many views take the latency-oriented form of the update kernel (kernels.hpp)
+constexpr int kUpdSmallViews = 4096;
+
 template <int L, typename T>
 int launch_update_backsub_t(calib_handle_s* h) {
+    if (h->nv <= kUpdSmallViews) {
+        const int blocks = std::max(1, (h->nv + kUpdViewsPerBlock - 1) / kUpdViewsPerBlock);    // one view per 16-lane group
+        hipLaunchKernelGGL((update_backsub_small_kernel<L, T>), dim3(blocks), dim3(kUpdThreads), 0, h->stream,
+                           h->G[0].p, h->G[1].p, st_cur(h), st_next(h), h->red, view_items(h), h->view_ext.p, h->nv,
+                           h->P[0].p, h->P[1].p, h->trace.p, reinterpret_cast<T*>(h->VC.p));
+        LAUNCHED(h, "update_backsub_small_kernel");
+        return CALIB_OK;
+    }
     const int per = kSchurThreads / 16;
     const int blocks = std::max(1, std::min(2048, (h->nv + per - 1) / per));     // grid-stride over views
     hipLaunchKernelGGL((update_backsub_kernel<L, T>), dim3(blocks), dim3(kSchurThreads), 0, h->stream, h->G[0].p,

@@ -662,7 +662,7 @@ constexpr int kSchurBlock = 256;
 constexpr int kSchurViewsPerBlock = kSchurBlock / 16;
 
 template <int L>
-__global__ __launch_bounds__(kSchurBlock) void schur_kernel(const double* __restrict__ G0,
+__global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __restrict__ G0,
                                                             const double* __restrict__ G1,
                                                             const LMState* __restrict__ st,
                                                             const int* __restrict__ view_item0,
@@ -672,13 +672,10 @@ __global__ __launch_bounds__(kSchurBlock) void schur_kernel(const double* __rest
     constexpr int kNfail = 2 * L * L + 2 * L, kSse = kNfail + 1;
     __shared__ double sfail[kSchurViewsPerBlock];
     __shared__ double stile[kSchurBlock / 64][256];
-    if (st->done) return;
-    const int variant = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = tid & 15, grp = tid >> 4, k = lane >> 4;
-    const bool boot = st->round == 0;
-    const int cand = st->cur ^ 1;
 
-    if (variant == 2) {
+    if (blockIdx.y == 2) {
+        if (st->done) return;
         // thread t of each half-block owns one field of the workgroup partials of B, g_c, sum r^2
         constexpr int NF = L * L + L + 1;
         double* out = part + (int64_t)blockIdx.x * VA;
@@ -706,34 +703,47 @@ __global__ __launch_bounds__(kSchurBlock) void schur_kernel(const double* __rest
         return;
     }
 
+    // blockIdx.y = 0 / 1 is the BUFFER the block eliminates (G0 / G1), known at launch: the first views' heads
+    // are requested before the LM state -- which says whether that buffer holds the candidate (variant A) or the
+    // current blocks (variant B) -- has arrived, one memory latency instead of two dependent ones
+    const double* G = blockIdx.y ? G1 : G0;
+    double V[21], b[6];
+    int v0 = blockIdx.x * kSchurViewsPerBlock;
+    if (v0 + grp < nv) {
+        // view_item0 == nullptr: every view is a single item (item index == view index)
+        const int v = v0 + grp, i0 = view_item0 ? view_item0[v] : v;
+        load_view_head<L>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
+    }
+    if (st->done) return;
+    const bool boot = st->round == 0;
+    const int cand = st->cur ^ 1;
+    const int variant = (int)blockIdx.y == cand ? 0 : 1;
     double* out = part + ((int64_t)variant * gridDim.x + blockIdx.x) * VA;
     if (variant == 1 && boot) {       // no "current" blocks yet
         for (int i = tid; i < VA; i += kSchurBlock) out[i] = 0.0;
         return;
     }
-    const int buf = variant == 0 ? cand : st->cur;
-    const double* G = buf ? G1 : G0;
     const double lam = variant == 0 ? (boot ? st->lam : st->lam / 10) : st->lam * 10;
 
     d4 acc = {0.0, 0.0, 0.0, 0.0};
     double nfail = 0.0;
-    for (int v0 = blockIdx.x * kSchurViewsPerBlock; v0 < nv; v0 += gridDim.x * kSchurViewsPerBlock) {
-        const int v = v0 + grp;
+    while (v0 < nv) {
         double z[6];
 #pragma unroll
         for (int m = 0; m < 6; ++m) z[m] = 0.0;
-        if (v < nv) {                                         // whole 16-lane group together
-            // view_item0 == nullptr: every view is a single item (item index == view index)
-            const int i0 = view_item0 ? view_item0[v] : v;
-            double V[21], b[6], invd[6];
-            load_view_head<L>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
+        if (v0 + grp < nv) {                                  // whole 16-lane group together
+            double invd[6];
             const bool ok = eliminate(V, b, lam, invd, z);
             if (c > L) {                                      // lanes above the gradient column contribute nothing
 #pragma unroll
                 for (int m = 0; m < 6; ++m) z[m] = 0.0;
             }
-            const bool fail = !ok;
-            if (fail) nfail += 1.0;
+            if (!ok) nfail += 1.0;
+        }
+        v0 += gridDim.x * kSchurViewsPerBlock;
+        if (v0 + grp < nv) {                                  // the next trip's heads, behind this trip's MFMAs
+            const int v = v0 + grp, i0 = view_item0 ? view_item0[v] : v;
+            load_view_head<L>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
         }
         // W^T W: K-slot k = this lane's view, six rows per view
 #pragma unroll
@@ -841,7 +851,6 @@ __device__ __forceinline__ double peer_sum(const PeerExchange& x, int i, double 
 __global__ __launch_bounds__(64) void reduce_kernel(const double* __restrict__ part, int nblocks, int VA,
                                                     const LMState* __restrict__ st,
                                                     double* __restrict__ red, PeerExchange x) {
-    if (st->done) return;
     const int i = blockIdx.x, lane = threadIdx.x;
     const int variant = i / VA, idx = i - variant * VA;
     const double* src = part + (int64_t)variant * nblocks * VA + idx;
@@ -860,6 +869,8 @@ __global__ __launch_bounds__(64) void reduce_kernel(const double* __restrict__ p
     double t = v[0];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    // the finished flag is looked at only now: its load travels with the partials' instead of ahead of them
+    if (st->done) return;
     if (x.world > 1) t = peer_sum(x, i, __shfl(t, 0, 64), lane);
     if (lane == 0) red[i] = t;
 }
@@ -1152,43 +1163,13 @@ __device__ __forceinline__ bool lm_update_step(const LMState* __restrict__ in, L
 // the next candidate P[cur^1] = P[cur] + delta, (c) turns the candidate's Euler angles (degrees)
 // into the rotation / derivative-axis constants the next round's point kernels read (what
 // view_setup_kernel does for round 0).
+// The rest of a view's update once its block is factored (V: Cholesky factor, invd, z from eliminate):
+// back-substitution, the view's part of the next candidate, and the candidate's view constants.
 template <int L, typename T>
-__global__ __launch_bounds__(kSchurThreads, 4) void update_backsub_kernel(
-        const double* __restrict__ G0, const double* __restrict__ G1, const LMState* __restrict__ st_in,
-        LMState* __restrict__ st_out, const double* __restrict__ red, const int* __restrict__ view_item0,
-        const int* __restrict__ view_ext, int nv, double* __restrict__ P0, double* __restrict__ P1,
-        double* __restrict__ trace, T* __restrict__ VC) {
-    const int tid = threadIdx.x, c = tid & 15;
-    const bool writer = blockIdx.x == 0 && tid < 16;
-    // the first 16-lane group of every workgroup takes the decision and solves; the others get
-    // (go, cur, lambda, dc) through LDS
-    __shared__ double sdec[L + 3];
-    int cur = 0;
-    double lam = 0.0, dc[L];
-    if (tid < 16) {
-        const bool go = lm_update_step<L>(st_in, st_out, red, P0, P1, trace, writer, c, cur, lam, dc);
-        if (c == 0) { sdec[0] = go ? 1.0 : 0.0; sdec[1] = (double)cur; sdec[2] = lam; }
-        if (c < L) {
-            double dci = 0.0;
-#pragma unroll
-            for (int j = 0; j < L; ++j) if (j == c) dci = dc[j];
-            sdec[3 + c] = dci;
-        }
-    }
-    __syncthreads();
-    if (sdec[0] == 0.0) return;
-    cur = (int)sdec[1];
-    lam = sdec[2];
-    const double coef = c < L ? -sdec[3 + c] : (c == L ? 1.0 : 0.0);
-    const double* G = cur ? G1 : G0;
-    const double* Pc = cur ? P1 : P0;
-    double* Pn = cur ? P0 : P1;
-    // grid-stride over views: the decision / solve above is paid once per workgroup, not per view
-    for (int v = blockIdx.x * (kSchurThreads / 16) + (tid >> 4); v < nv; v += gridDim.x * (kSchurThreads / 16)) {
-    double V[21], b[6], invd[6], z[6];
-    const int i0 = view_item0 ? view_item0[v] : v;
-    load_view_head<L>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
-    eliminate(V, b, lam, invd, z);
+__device__ __forceinline__ void finish_view(const double (&V)[21], const double (&invd)[6], const double (&z)[6],
+                                            double coef, int c, int v, const int* __restrict__ view_ext,
+                                            const double* __restrict__ Pc, double* __restrict__ Pn,
+                                            T* __restrict__ VC) {
     // w = Lc^-1 (g_v - E^T dc): lane c < L carries -dc[c] z_c, lane L the gradient's z_g
     double w[6];
 #pragma unroll
@@ -1237,7 +1218,108 @@ __global__ __launch_bounds__(kSchurThreads, 4) void update_backsub_kernel(
     T* dst = VC + (int64_t)v * kViewStride;
     dst[c] = (T)mine;
     if (c < 2) dst[16 + c] = (T)(c == 0 ? o18[16] : o18[17]);
+}
+
+template <int L, typename T>
+__global__ __launch_bounds__(kSchurThreads, 4) void update_backsub_kernel(
+        const double* __restrict__ G0, const double* __restrict__ G1, const LMState* __restrict__ st_in,
+        LMState* __restrict__ st_out, const double* __restrict__ red, const int* __restrict__ view_item0,
+        const int* __restrict__ view_ext, int nv, double* __restrict__ P0, double* __restrict__ P1,
+        double* __restrict__ trace, T* __restrict__ VC) {
+    const int tid = threadIdx.x, c = tid & 15;
+    const bool writer = blockIdx.x == 0 && tid < 16;
+    // the first 16-lane group of every workgroup takes the decision and solves; the others get
+    // (go, cur, lambda, dc) through LDS
+    __shared__ double sdec[L + 3];
+    int cur = 0;
+    double lam = 0.0, dc[L];
+    if (tid < 16) {
+        const bool go = lm_update_step<L>(st_in, st_out, red, P0, P1, trace, writer, c, cur, lam, dc);
+        if (c == 0) { sdec[0] = go ? 1.0 : 0.0; sdec[1] = (double)cur; sdec[2] = lam; }
+        if (c < L) {
+            double dci = 0.0;
+#pragma unroll
+            for (int j = 0; j < L; ++j) if (j == c) dci = dc[j];
+            sdec[3 + c] = dci;
+        }
     }
+    __syncthreads();
+    if (sdec[0] == 0.0) return;
+    cur = (int)sdec[1];
+    lam = sdec[2];
+    const double coef = c < L ? -sdec[3 + c] : (c == L ? 1.0 : 0.0);
+    const double* G = cur ? G1 : G0;
+    const double* Pc = cur ? P1 : P0;
+    double* Pn = cur ? P0 : P1;
+    // grid-stride over views: the decision / solve above is paid once per workgroup, not per view
+    for (int v = blockIdx.x * (kSchurThreads / 16) + (tid >> 4); v < nv; v += gridDim.x * (kSchurThreads / 16)) {
+        double V[21], b[6], invd[6], z[6];
+        const int i0 = view_item0 ? view_item0[v] : v;
+        load_view_head<L>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
+        eliminate(V, b, lam, invd, z);
+        finish_view<L, T>(V, invd, z, coef, c, v, view_ext, Pc, Pn, VC);
+    }
+}
+
+// The same round step for SMALL shards (one view per 16-lane group, a single trip), where the launch is a chain
+// of latencies rather than work: wave 0 of a workgroup is the SOLVER (its first 16 lanes: decision + L x L
+// solve), the other kUpdViewWaves waves own views. The accept / reject decision itself needs two scalars
+// (err(candidate) from the reduce buffer, err(current) from the state), so the view waves take it redundantly
+// and request and eliminate their view's block WHILE the solver works; they meet at the barrier, where dc
+// arrives through LDS. (For large shards the idle solver lanes and the registers of two code paths cost more
+// than the overlap gives: c3 +1.5 us, c5 +12 us; c2 -1.2 us.)
+constexpr int kUpdViewWaves = 4;
+constexpr int kUpdThreads = 64 * (1 + kUpdViewWaves);
+constexpr int kUpdViewsPerBlock = kUpdViewWaves * 4;
+
+template <int L, typename T>
+__global__ __launch_bounds__(kUpdThreads) void update_backsub_small_kernel(
+        const double* __restrict__ G0, const double* __restrict__ G1, const LMState* __restrict__ st_in,
+        LMState* __restrict__ st_out, const double* __restrict__ red, const int* __restrict__ view_item0,
+        const int* __restrict__ view_ext, int nv, double* __restrict__ P0, double* __restrict__ P1,
+        double* __restrict__ trace, T* __restrict__ VC) {
+    constexpr int kSse = 2 * L * L + 2 * L + 1;
+    const int tid = threadIdx.x, c = tid & 15, wave = tid >> 6;
+    const bool writer = blockIdx.x == 0 && tid < 16;
+    __shared__ double sdec[L + 3];
+    int cur = 0;
+    double lam = 0.0;
+    double V[21], b[6], invd[6], z[6];
+    const int v = blockIdx.x * kUpdViewsPerBlock + ((tid - 64) >> 4);       // one trip: gridDim.x covers the views
+    if (wave == 0) {
+        if (tid < 16) {
+            double dc[L];
+            const bool go = lm_update_step<L>(st_in, st_out, red, P0, P1, trace, writer, c, cur, lam, dc);
+            if (c == 0) { sdec[0] = go ? 1.0 : 0.0; sdec[1] = (double)cur; sdec[2] = lam; }
+            if (c < L) {
+                double dci = 0.0;
+#pragma unroll
+                for (int j = 0; j < L; ++j) if (j == c) dci = dc[j];
+                sdec[3 + c] = dci;
+            }
+        }
+    } else {
+        // the decision of lm_update_step (src/calibrate.py:155-168), from the same two numbers
+        cur = st_in->cur;
+        lam = st_in->lam;
+        if (st_in->round == 0) {
+            cur ^= 1;
+        } else if (red[kSse] < st_in->err_cur) {
+            cur ^= 1;
+            lam = lam / 10;
+        } else {
+            lam = lam * 10;
+        }
+        if (v < nv) {
+            const int i0 = view_item0 ? view_item0[v] : v;
+            load_view_head<L>(cur ? G1 : G0, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
+            eliminate(V, b, lam, invd, z);
+        }
+    }
+    __syncthreads();
+    if (sdec[0] == 0.0 || wave == 0 || v >= nv) return;
+    const double coef = c < L ? -sdec[3 + c] : (c == L ? 1.0 : 0.0);
+    finish_view<L, T>(V, invd, z, coef, c, v, view_ext, cur ? P1 : P0, cur ? P0 : P1, VC);
 }
 
 // ---------------------------------------------------------------- per-view homography LM
