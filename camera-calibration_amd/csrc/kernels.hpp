@@ -442,58 +442,49 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
                 }
                 __builtin_amdgcn_wave_barrier();
                 const int rows = qend - (q0 + ROWS * half);     // valid points in this pass (may exceed ROWS)
-                if (rows >= ROWS) {
-                    // full pass: no tests between the LDS reads and the MFMAs, so the operand reads go
-                    // out together and the two accumulators (u rows, v rows) are fed back to back
-                    T2 jv[ROWS / 4];
+                if constexpr (MF32) {
+                    // fp32 storage: the pass's 32 points are contracted by v_mfma_f32_16x16x4_f32 (twice the fp64
+                    // rate) into fp32 tiles that start at zero, and the tiles are added to the fp64 accumulators:
+                    // fp32 rounding stays confined to sums of 32 products
+                    f4 fu = {0.f, 0.f, 0.f, 0.f}, fv = {0.f, 0.f, 0.f, 0.f};
+                    if (rows >= ROWS) {
+                        T2 jv[ROWS / 4];
 #pragma unroll
-                    for (int s = 0; s < ROWS / 4; ++s) jv[s] = slab[(4 * s + k) * RS + c];
-                    if constexpr (MF32) {
-                        // fp32 storage: the pass's 32 points are contracted by v_mfma_f32_16x16x4_f32 (twice the fp64
-                        // rate) into fp32 tiles that start at zero, and the tiles are added to the fp64 accumulators:
-                        // fp32 rounding stays confined to sums of 32 products
-                        f4 fu = {0.f, 0.f, 0.f, 0.f}, fv = {0.f, 0.f, 0.f, 0.f};
+                        for (int s = 0; s < ROWS / 4; ++s) jv[s] = slab[(4 * s + k) * RS + c];
 #pragma unroll
                         for (int s = 0; s < ROWS / 4; ++s) {
                             fu = __builtin_amdgcn_mfma_f32_16x16x4f32(jv[s].x, jv[s].x, fu, 0, 0, 0);
                             fv = __builtin_amdgcn_mfma_f32_16x16x4f32(jv[s].y, jv[s].y, fv, 0, 0, 0);
                         }
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) { acc[reg] += (double)fu[reg]; acc2[reg] += (double)fv[reg]; }
                     } else {
 #pragma unroll
                         for (int s = 0; s < ROWS / 4; ++s) {
-                            const double jx = (double)jv[s].x, jy = (double)jv[s].y;
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jx, jx, acc, 0, 0, 0);
-                            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc2, 0, 0, 0);
+                            if (4 * s >= rows) break;                   // wave-uniform
+                            T2 ja = slab[(4 * s + k) * RS + c];
+                            if (4 * s + k >= rows) { ja.x = T(0); ja.y = T(0); }    // points past the end of the last group
+                            fu = __builtin_amdgcn_mfma_f32_16x16x4f32(ja.x, ja.x, fu, 0, 0, 0);
+                            fv = __builtin_amdgcn_mfma_f32_16x16x4f32(ja.y, ja.y, fv, 0, 0, 0);
                         }
-                    }
-                } else if constexpr (MF32) {
-                    // partial pass
-                    f4 fu = {0.f, 0.f, 0.f, 0.f}, fv = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int s = 0; s < ROWS / 4; ++s) {
-                        if (4 * s >= rows) break;                   // wave-uniform
-                        T2 ja = slab[(4 * s + k) * RS + c];
-                        if (4 * s + k >= rows) { ja.x = T(0); ja.y = T(0); }    // points past the end of the last group
-                        fu = __builtin_amdgcn_mfma_f32_16x16x4f32(ja.x, ja.x, fu, 0, 0, 0);
-                        fv = __builtin_amdgcn_mfma_f32_16x16x4f32(ja.y, ja.y, fv, 0, 0, 0);
                     }
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) { acc[reg] += (double)fu[reg]; acc2[reg] += (double)fv[reg]; }
                 } else {
-                    // partial pass: two groups per trip (the second may lie past the end: stale rows, skipped)
-#pragma unroll
-                    for (int s = 0; s < ROWS / 4; s += 2) {
-                        if (4 * s >= rows) break;                   // wave-uniform
-                        const T2 ja = slab[(4 * s + k) * RS + c], jb = slab[(4 * s + 4 + k) * RS + c];
-                        double jx = (double)ja.x, jy = (double)ja.y;
-                        if (4 * s + k >= rows) { jx = 0.0; jy = 0.0; }          // points past the end of the last group
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jx, jx, acc, 0, 0, 0);
-                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc2, 0, 0, 0);
-                        if (4 * s + 4 >= rows) break;               // wave-uniform
-                        jx = (double)jb.x; jy = (double)jb.y;
-                        if (4 * s + 4 + k >= rows) { jx = 0.0; jy = 0.0; }
+                    // ONE rolled loop over the pass's complete 4-point groups, full pass or not: the two accumulators
+                    // stay in the same registers from the first batch to the last (with a separate path for full
+                    // passes the compiler shuttled both tiles between two register sets around every pass -- 16
+                    // v_mov_b64 behind a drained matrix pipe), at the price of one address add per group
+                    const int nfull = rows >= ROWS ? ROWS / 4 : rows >> 2;
+                    const T2* src = slab + k * RS + c;
+                    for (int s = 0; s < nfull; ++s) {
+                        const T2 ja = *src;
+                        src += 4 * RS;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ja.x, (double)ja.x, acc, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ja.y, (double)ja.y, acc2, 0, 0, 0);
+                    }
+                    if (rows < ROWS && (rows & 3)) {            // wave-uniform: the last, incomplete group
+                        const T2 ja = *src;
+                        const bool live = 4 * nfull + k < rows;
+                        const double jx = live ? (double)ja.x : 0.0, jy = live ? (double)ja.y : 0.0;
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jx, jx, acc, 0, 0, 0);
                         acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc2, 0, 0, 0);
                     }
