@@ -10,7 +10,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcalib_lm.so")
+LIB_PATH = os.environ.get("CALIB_LM_LIBRARY") or os.path.join(_HERE, "lib", "libcalib_lm.so")
 
 MODEL_RADTAN, MODEL_FISHEYE = 0, 1
 DTYPE_F64, DTYPE_F32 = 0, 1

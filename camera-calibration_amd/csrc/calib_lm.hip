@@ -349,11 +349,23 @@ int launch_fused_t(calib_handle_s* h, const LMState* st, int sel) {
     const int ipb = 4 / wpi;
     const int blocks = (h->n_items + ipb - 1) / ipb;
     int pi = prof_begin(h, 2);
-    hipLaunchKernelGGL((fused_kernel<MODEL, T, 32, 4>), dim3(blocks), dim3(256), 0, h->stream, h->P[0].p,
-                       h->P[1].p, reinterpret_cast<const T2*>(h->uv.p), reinterpret_cast<const T2*>(h->XY.p),
-                       reinterpret_cast<const T*>(h->Z.p), reinterpret_cast<const T*>(h->VC.p), h->item_pt0.p,
-                       h->item_n.p, h->item_view.p, h->n_items, wpi, h->emit_tab.p, st, sel, h->G[0].p, h->G[1].p,
-                       h->bpart.p);
+    // fp64 items of more than two batches build J^T J from 4x4 blocks (v_mfma_f64_4x4x4_4b, symmetric half only;
+    // c3 -4.5 %); shorter items stay on the 16x16x4 form, whose record goes to HBM straight from the accumulators
+    // (one-batch items: c2 +4 % on the block form; two batches, c5: no difference)
+    const bool g44 = sizeof(T) == 8 && h->MN > (int64_t)128 * h->n_items;
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, h->stream, h->P[0].p,
+                           h->P[1].p, reinterpret_cast<const T2*>(h->uv.p), reinterpret_cast<const T2*>(h->XY.p),
+                           reinterpret_cast<const T*>(h->Z.p), reinterpret_cast<const T*>(h->VC.p), h->item_pt0.p,
+                           h->item_n.p, h->item_view.p, h->n_items, wpi, h->emit_tab.p, st, sel, h->G[0].p, h->G[1].p,
+                           h->bpart.p);
+    };
+    if constexpr (sizeof(T) == 8) {
+        if (g44) launch(fused_kernel<MODEL, T, 32, 4, true>);
+        else launch(fused_kernel<MODEL, T, 32, 4, false>);
+    } else {
+        launch(fused_kernel<MODEL, T, 32, 4, false>);
+    }
     prof_end(h, pi);
     h->n_bpart = blocks;
     LAUNCHED(h, "fused_kernel");

@@ -348,7 +348,7 @@ constexpr int kFusedRowChunks = 17;                       // 16 columns + 1 pad 
 
 // ROWS = points transposed per LDS pass (32: two passes per 64-point batch, half the lanes
 // writing each time; 64: one pass, twice the LDS). WAVES = waves per workgroup.
-template <int MODEL, typename T, int ROWS, int WAVES>
+template <int MODEL, typename T, int ROWS, int WAVES, bool G44>
 __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) void fused_kernel(const double* __restrict__ P0, const double* __restrict__ P1,
                                                     const typename Pair<T>::type* __restrict__ uv,
                                                     const typename Pair<T>::type* __restrict__ XY,
@@ -363,7 +363,15 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
     using T2 = typename Pair<T>::type;
     constexpr int C = ModelTraits<MODEL>::C;
     constexpr int RS = kFusedRowChunks;
-    constexpr int SLAB = ROWS * RS;                        // ROWS point rows of 16 (du, dv) chunks + 1 pad chunk
+    constexpr bool MF32 = sizeof(T) == 4;                  // fp32 storage: fp32 MFMA per pass, fp64 across passes
+    // Row r of a wave's slab starts at chunk rowOff(r). fp32 storage: 16 chunks + 1 pad chunk per row. fp64: 16
+    // chunks per row and one pad chunk per PAIR of rows, so that rows 2 m and 2 m + 1 share their bank phase: the
+    // four 16-lane groups a ds_read_b128 is served in each hold the column sets {0-3, 12-15} of an even and {4-11}
+    // of the odd row of a pair (or the other way round) -- 16 distinct chunk phases exactly when the two rows are
+    // in phase. (With a pad chunk per row every group had one 2-way conflict: 8 LDS cycles per read instead of 4.)
+    // Stores stay conflict-free because a point is not processed by lane = row: see sl below.
+    constexpr int SLAB = MF32 ? ROWS * RS : ROWS * 16 + ROWS / 2;
+    auto rowOff = [](int r) { return MF32 ? r * RS : r * 16 + (r >> 1); };
     constexpr int HALVES = 64 / ROWS;
     constexpr bool RCOL = C < 16;                          // a free 16th MFMA column: J^T r and sum r^2 for free
     // C == 16 (radial-tangential): columns 3 and 4 of J are the constants (1,0) and (0,1). With the u rows
@@ -371,7 +379,6 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
     // tile_v[.][3] = sum Jv, i.e. what columns 3 and 4 used to give -- and column 4 the residual
     // (ru, rv): (tile_u + tile_v)[.][4] = J^T r, [4][4] = sum r^2, tile_u[3][4] = sum ru, tile_v[3][4] = sum rv.
     constexpr bool ONES = !RCOL;
-    constexpr bool MF32 = sizeof(T) == 4;                  // fp32 storage: fp32 MFMA per pass, fp64 across passes
     // one slab per wave; after the main loop the same memory holds the wave's two accumulator tiles
     __shared__ __attribute__((aligned(16))) unsigned char smem[WAVES * SLAB * sizeof(T2)];
     if (sel && st->done) return;
@@ -383,8 +390,16 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
     const int item = blockIdx.x * (WAVES >> lw) + (wave >> lw);
     const bool valid = item < n_items;
     const int c = lane & 15, k = lane >> 4;
+    // Lane l evaluates point sl(l) of its batch and stores row sl(l): inside each 16-lane block lanes 0-7 take the
+    // even rows, lanes 8-15 the odd ones. A ds_write_b128 is served 8 consecutive lanes at a time; their rows
+    // 0, 2, .. 14 (or 1, 3, .. 15) have 8 different bank phases in the fp64 layout above. Rows stay in point order,
+    // so the contraction (which groups rows 4 s .. 4 s + 3) and the handling of the last, partial batch do not care.
+    const int sl = MF32 ? lane : ((lane & 48) | ((lane & 7) << 1) | ((lane >> 3) & 1));
     T2* slab = reinterpret_cast<T2*>(smem) + wave * SLAB;
     d4 acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+    // fp64: the Gram is built from 4x4 blocks by v_mfma_f64_4x4x4_4b (see the contraction below): per row kind
+    // (u, v) the diagonal blocks (b, b), the blocks (b, b+1) and the blocks (b, b+2) of the 4 x 4 block grid
+    double d0u = 0.0, d0v = 0.0, d1u = 0.0, d1v = 0.0, d2u = 0.0;
     if (valid) {
         const int64_t pbeg = item_pt0[item];
         const int n = item_n[item];
@@ -400,19 +415,19 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
             T2 c3, c4;
             c3.x = T(1); c3.y = ONES ? T(1) : T(0);
             c4.x = T(0); c4.y = T(1);
-            slab[lane * RS + 3] = c3;
-            if (!ONES) slab[lane * RS + 4] = c4;
+            slab[rowOff(lane) + 3] = c3;
+            if (!ONES) slab[rowOff(lane) + 4] = c4;
             // columns 0, 1, 2 are (xd, 0), (0, yd), (yd, 0): their zero halves are set once, the batches
             // store only the other 8 bytes
-            T* zr = reinterpret_cast<T*>(slab + lane * RS);
+            T* zr = reinterpret_cast<T*>(slab + rowOff(lane));
             zr[1] = T(0); zr[2] = T(0); zr[5] = T(0);
         }
         // inputs of the next batch are requested before the current batch is evaluated
-        int64_t pn = pbeg + (qbeg + lane < qend ? qbeg + lane : qend - 1);
+        int64_t pn = pbeg + (qbeg + sl < qend ? qbeg + sl : qend - 1);
         T2 m_n = uv[pn], xy_n = XY[pn];
         T z_n = Z[pn];
         for (int q0 = qbeg; q0 < qend; q0 += 64) {
-            const int q = q0 + lane;
+            const int q = q0 + sl;
             const T2 m = m_n, xy = xy_n;
             const T z = z_n;
             if (q0 + 64 < qend) {
@@ -432,7 +447,7 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
                 if (q0 + ROWS * half >= qend) break;            // wave-uniform
                 __builtin_amdgcn_wave_barrier();
                 if (HALVES == 1 || (lane >> 5) == half) {
-                    T2* row = slab + (lane & (ROWS - 1)) * RS;
+                    T2* row = slab + rowOff(sl & (ROWS - 1));
                     T* rh = reinterpret_cast<T*>(row);
                     rh[0] = Jc[0].x; rh[3] = Jc[1].y; rh[4] = Jc[2].x;  // the non-zero halves of columns 0, 1, 2
 #pragma unroll
@@ -468,16 +483,14 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
                     }
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) { acc[reg] += (double)fu[reg]; acc2[reg] += (double)fv[reg]; }
-                } else {
-                    // ONE rolled loop over the pass's complete 4-point groups, full pass or not: the two accumulators
-                    // stay in the same registers from the first batch to the last (with a separate path for full
-                    // passes the compiler shuttled both tiles between two register sets around every pass -- 16
-                    // v_mov_b64 behind a drained matrix pipe), at the price of one address add per group
+                } else if constexpr (!G44) {
+                    // fp64, 16x16x4 form (items of a single batch): ONE rolled loop over the pass's complete 4-point
+                    // groups, full pass or not, keeps the two accumulator tiles in the same registers all the way
                     const int nfull = rows >= ROWS ? ROWS / 4 : rows >> 2;
-                    const T2* src = slab + k * RS + c;
+                    const T2* src = slab + rowOff(k) + c;              // rows 4 s + k: + 66 chunks per group
                     for (int s = 0; s < nfull; ++s) {
                         const T2 ja = *src;
-                        src += 4 * RS;
+                        src += 66;
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ja.x, (double)ja.x, acc, 0, 0, 0);
                         acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ja.y, (double)ja.y, acc2, 0, 0, 0);
                     }
@@ -487,6 +500,50 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
                         const double jx = live ? (double)ja.x : 0.0, jy = live ? (double)ja.y : 0.0;
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jx, jx, acc, 0, 0, 0);
                         acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc2, 0, 0, 0);
+                    }
+                } else {
+                    // fp64, 4x4x4 form (items of several batches). v_mfma_f64_16x16x4_f64 is held to ~46 TFLOP/s by the chip (tools/ubench/ubench6: 36 cycles
+                    // per instruction on a few CUs, ~105 with every CU issuing them), v_mfma_f64_4x4x4_4b -- four
+                    // independent 4x4x4 products per instruction -- sustains 76 (ubench8), and J^T J is symmetric. So the
+                    // 16 x 16 tile is built from 4 x 4 blocks: lane (k, b, x) = (lane >> 4, (lane >> 2) & 3, lane & 3)
+                    // supplies A = J[point k][4 b + x] and B = J[point k][4 b' + x] and receives
+                    // D[4 b + k'][4 b' + x] in lane (k', b, x) (layout: tools/ubench/mfma4x4_layout). With b' = b the
+                    // four diagonal blocks, b' = b + 1 the blocks (0,1) (1,2) (2,3) (3,0), b' = b + 2 the blocks (0,2)
+                    // (1,3) and their transposes: every block of the symmetric tile or its transpose, 6 x 256 MACs per
+                    // 4 points instead of 2 x 1024. The A operand is the same (u, v) chunk the 16x16x4 form read
+                    // (column c = lane & 15 of point k); the two B operands are columns c + 4 and c + 8 of the same row.
+                    // ONE rolled loop, full pass or not: the accumulators stay in the same registers all the way.
+                    // Five instructions per group of 4 points: (b,b) and (b,b+1) for the u rows and for the v rows, and
+                    // ONE for the (b,b+2) blocks: slots b = 0, 1 take them for the u rows, slots b = 2, 3 -- whose
+                    // (b,b+2) blocks are the transposes (2,0), (3,1) of the same two -- for the v rows. Its operands are
+                    // 8-byte reads of the lane's own chunk and of chunk c + 8 at the u or the v half (jh, per lane).
+                    const int nfull = rows >= ROWS ? ROWS / 4 : rows >> 2;
+                    const T2* src = slab + rowOff(k);                  // rows 4 s + k: + 66 chunks per group
+                    const int c1 = (c + 4) & 15, c2 = (c + 8) & 15, jh = (lane >> 3) & 1;      // jh = 1: blocks 2, 3
+                    const T* h0 = reinterpret_cast<const T*>(src + c) + jh;
+                    const T* h2 = reinterpret_cast<const T*>(src + c2) + jh;
+                    auto contract = [&](const T2& ja, const T2& jb, double ha, double hc) {
+                        d0u = __builtin_amdgcn_mfma_f64_4x4x4f64((double)ja.x, (double)ja.x, d0u, 0, 0, 0);
+                        d0v = __builtin_amdgcn_mfma_f64_4x4x4f64((double)ja.y, (double)ja.y, d0v, 0, 0, 0);
+                        d1u = __builtin_amdgcn_mfma_f64_4x4x4f64((double)ja.x, (double)jb.x, d1u, 0, 0, 0);
+                        d1v = __builtin_amdgcn_mfma_f64_4x4x4f64((double)ja.y, (double)jb.y, d1v, 0, 0, 0);
+                        d2u = __builtin_amdgcn_mfma_f64_4x4x4f64(ha, hc, d2u, 0, 0, 0);
+                    };
+                    if (rows >= ROWS) {
+                        // full pass: every address is the wave's constant base plus an immediate
+#pragma unroll
+                        for (int s = 0; s < ROWS / 4; ++s)
+                            contract(src[66 * s + c], src[66 * s + c1], (double)h0[2 * 66 * s], (double)h2[2 * 66 * s]);
+                    } else {
+                        for (int s = 0; s < nfull; ++s)
+                            contract(src[66 * s + c], src[66 * s + c1], (double)h0[2 * 66 * s], (double)h2[2 * 66 * s]);
+                        if (rows & 3) {                                 // wave-uniform: the last, incomplete group
+                            const bool live = 4 * nfull + k < rows;
+                            T2 ja = src[66 * nfull + c], jb = src[66 * nfull + c1];
+                            double ha = (double)h0[2 * 66 * nfull], hc = (double)h2[2 * 66 * nfull];
+                            if (!live) { ja.x = T(0); ja.y = T(0); jb.x = T(0); jb.y = T(0); ha = 0.0; hc = 0.0; }
+                            contract(ja, jb, ha, hc);
+                        }
                     }
                 }
             }
@@ -500,7 +557,7 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
     double* TU = reinterpret_cast<double*>(slab);
     double* TV = TU + kEmitTile;
     double* Gbase = sel ? ((st->cur ^ 1) ? G1 : G0) : G0;
-    if (wpi == 1 && valid) {
+    if (!G44 && wpi == 1 && valid) {
         // One wave per item: the item's record goes to HBM straight from the accumulators (lane (k, c) holds rows
         // k + 4 reg -- 4 k + reg behind the fp32 MFMA -- of column c; 16 lanes store 128 contiguous bytes): rows
         // L..L+5 of J^T J, then J^T r and sum r^2 from the residual's row. No table, no LDS, nothing to wait for.
@@ -530,12 +587,25 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
         }
     }
     __builtin_amdgcn_wave_barrier();                            // the slab is this wave's own: no workgroup barrier needed yet
+    if constexpr (!G44) {
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        // C/D register -> tile row: fp64 MFMA k + 4 reg, fp32 MFMA (whose tiles the accumulators mirror) 4 k + reg
-        const int row = MF32 ? 4 * k + reg : k + 4 * reg;
-        TU[row * 16 + c] = acc[reg];
-        TV[row * 16 + c] = acc2[reg];
+        for (int reg = 0; reg < 4; ++reg) {
+            // C/D register -> tile row: fp64 MFMA k + 4 reg, fp32 MFMA (whose tiles the accumulators mirror) 4 k + reg
+            const int row = MF32 ? 4 * k + reg : k + 4 * reg;
+            TU[row * 16 + c] = acc[reg];
+            TV[row * 16 + c] = acc2[reg];
+        }
+    } else {
+        // block results -> the full symmetric 16 x 16 tiles: lane (i, b, j) holds entry (4 b + i, 4 b' + j) of block (b, b')
+        const int bi = (lane >> 2) & 3, j = lane & 3;
+        const int row = 4 * bi + k, col0 = 4 * bi + j, col1 = 4 * ((bi + 1) & 3) + j, col2 = 4 * ((bi + 2) & 3) + j;
+        TU[row * 16 + col0] = d0u;  TV[row * 16 + col0] = d0v;
+        TU[row * 16 + col1] = d1u;  TV[row * 16 + col1] = d1v;
+        TU[col1 * 16 + row] = d1u;  TV[col1 * 16 + row] = d1v;  // the transposes of the (b, b+1) blocks
+        // (b, b+2): lanes of blocks 0, 1 hold the u rows' (0,2), (1,3), lanes of blocks 2, 3 the v rows' (2,0), (3,1)
+        double* T2nd = bi < 2 ? TU : TV;
+        T2nd[row * 16 + col2] = d2u;
+        T2nd[col2 * 16 + row] = d2u;
     }
     if (lane == 0) { TU[kEmitZero] = 0.0; TV[kEmitZero] = 0.0; }
     __syncthreads();
@@ -550,7 +620,7 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
         }
         part[(int64_t)blockIdx.x * kPartStride + threadIdx.x] = o;
     }
-    if (wpi == 1 || sub != 0 || !valid) return;                 // items split over waves: the first one assembles the record
+    if ((!G44 && wpi == 1) || sub != 0 || !valid) return;       // the item's first wave assembles the record from the parked tiles
     double* G = Gbase + (int64_t)item * kGStride;
     {
         const int i0 = 2 * lane;                                // kGStride = 128: one pass
