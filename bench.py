@@ -371,9 +371,15 @@ def main():
         if fusedN:
             fusedAvgMs = fusedMs / fusedN
             fusedPts = MNlocal
-            mfmaFlops = 4 * 16 * 16 * fusedPts               # 2 x v_mfma_f64_16x16x4 (2048 flop) per 4 points
-            # An fp64 MFMA blocks the VALU of every wave on its SIMD (tools/ubench; SQ_VALU_MFMA_COEXEC_CYCLES = 0)
-            # and matrix peak = vector peak: both kinds of fp64 work draw on the one 78.6 TFLOP/s budget.
+            # ALGORITHMIC matrix flops: J^T J as executed on full 16x16 tiles, 2 x 2048 flop per 4 points.
+            # fp64 items of more than two batches are contracted from 4x4 blocks instead (v_mfma_f64_4x4x4_4b, the
+            # symmetric half only: 5 x 512 flop per 4 points) -- `mfma_flops_executed_per_launch` says which.
+            mfmaFlops = 4 * 16 * 16 * fusedPts
+            blockForm = cfg["dtype"] == "f64" and shard["pointsPerView"] > 128
+            mfmaExecuted = (5 * 512 // 4 if blockForm else 4 * 16 * 16) * fusedPts
+            # Matrix and vector fp64 work draw on one budget: the data sheet gives both 78.6 TFLOP/s, and what the
+            # chip sustains with every CU busy is lower and depends on the instruction (tools/ubench/ubench6-8,
+            # profiles/r02_ubench.txt: v_mfma_f64_16x16x4 46, v_mfma_f64_4x4x4_4b 76, v_fma_f64 62 TFLOP/s).
             # `achieved` counts the VALU flops of every lane of every 64-lane batch the kernel executes;
             # `useful_frac` counts a view's last, partly filled batch only for its live lanes.
             batches = viewsPerGpu * (-(-shard["pointsPerView"] // 64))
@@ -384,15 +390,19 @@ def main():
             # fp32 storage (configs[3]): the Gram runs on v_mfma_f32_16x16x4_f32, priced against the fp32 matrix peak;
             # its fp32 VALU flops are not in profiles/pmc_fused.json, so `achieved` counts the matrix flops only
             peak = FP64_MATRIX_PEAK_TFLOPS if f64 else FP32_MATRIX_PEAK_TFLOPS
-            mainRoof = {"kernel": "fused_kernel (jacobian blocks + " + ("v_mfma_f64_16x16x4_f64" if f64 else "v_mfma_f32_16x16x4_f32")
-                                  + " J^T J, J on-chip)",
+            mfmaName = "v_mfma_f32_16x16x4_f32" if not f64 else ("v_mfma_f64_4x4x4_4b_f64" if blockForm else "v_mfma_f64_16x16x4_f64")
+            mainRoof = {"kernel": "fused_kernel (jacobian blocks + " + mfmaName + " J^T J, J on-chip)",
                         "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
                         "frac": tf / peak,
                         "useful_frac": (mfmaFlops + valuUseful) / (fusedAvgMs * 1e-3) / 1e12 / peak,
                         "traffic": fusedTraffic, "traffic_source": pmcSource if fusedTraffic else None,
-                        "mfma_flops_per_launch": mfmaFlops, "valu_fp64_flops_per_launch": valuFlops,
+                        "mfma_flops_per_launch": mfmaFlops, "mfma_flops_executed_per_launch": mfmaExecuted,
+                        "valu_fp64_flops_per_launch": valuFlops,
+                        "sustained_whole_chip_TFLOPs_measured": {"v_mfma_f64_16x16x4": 46.4, "v_mfma_f64_4x4x4_4b": 75.8,
+                                                                 "v_fma_f64": 61.8, "source": "profiles/r02_ubench.txt"},
                         "valu_flops_source": pmcSource if valuPerBatch else "none: profiles/pmc_fused.json has no entry",
                         "mfma_only_frac": mfmaFlops / (fusedAvgMs * 1e-3) / 1e12 / peak,
+                        "frac_executed": (mfmaExecuted + valuFlops) / (fusedAvgMs * 1e-3) / 1e12 / peak,
                         "points_per_launch": fusedPts,
                         "algorithmic_hbm_bytes_per_launch": 5 * w * fusedPts,
                         "avg_launch_ms": fusedAvgMs, "launches_timed": fusedN,

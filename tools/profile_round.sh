@@ -24,3 +24,8 @@ python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/prof/bench_c3_s20.j
 echo "bench c3 driver flags done"
 python3 bench.py > gpurun_out/prof/bench_c3.json 2> gpurun_out/prof/bench_c3.err
 echo "bench c3 done"
+# whole-chip fp64 pipe rates (tools/ubench/ubench6-8; binaries are built by hand, see the sources' headers)
+for u in ubench6 ubench7 ubench8 mfma4x4_layout; do
+  [ -x tools/ubench/$u ] && { echo "== $u"; tools/ubench/$u; } >> gpurun_out/prof/ubench.txt 2>&1
+done
+echo "ubench done"
