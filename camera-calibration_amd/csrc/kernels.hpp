@@ -502,21 +502,21 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
                         acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc2, 0, 0, 0);
                     }
                 } else {
-                    // fp64, 4x4x4 form (items of several batches). v_mfma_f64_16x16x4_f64 is held to ~46 TFLOP/s by the chip (tools/ubench/ubench6: 36 cycles
-                    // per instruction on a few CUs, ~105 with every CU issuing them), v_mfma_f64_4x4x4_4b -- four
-                    // independent 4x4x4 products per instruction -- sustains 76 (ubench8), and J^T J is symmetric. So the
-                    // 16 x 16 tile is built from 4 x 4 blocks: lane (k, b, x) = (lane >> 4, (lane >> 2) & 3, lane & 3)
-                    // supplies A = J[point k][4 b + x] and B = J[point k][4 b' + x] and receives
-                    // D[4 b + k'][4 b' + x] in lane (k', b, x) (layout: tools/ubench/mfma4x4_layout). With b' = b the
-                    // four diagonal blocks, b' = b + 1 the blocks (0,1) (1,2) (2,3) (3,0), b' = b + 2 the blocks (0,2)
-                    // (1,3) and their transposes: every block of the symmetric tile or its transpose, 6 x 256 MACs per
-                    // 4 points instead of 2 x 1024. The A operand is the same (u, v) chunk the 16x16x4 form read
-                    // (column c = lane & 15 of point k); the two B operands are columns c + 4 and c + 8 of the same row.
-                    // ONE rolled loop, full pass or not: the accumulators stay in the same registers all the way.
+                    // fp64, 4x4x4 form (items of several batches). With every CU issuing it, v_mfma_f64_16x16x4_f64 is
+                    // held to ~47 TFLOP/s by the chip (tools/ubench/ubench6: 0.54 TFLOP/s per CU on a few CUs, 0.19 on
+                    // all of them); v_mfma_f64_4x4x4_4b -- four independent 4x4x4 products per instruction -- sustains
+                    // 76 (ubench8), and J^T J is symmetric. So the 16 x 16 tile is built from 4 x 4 blocks: lane
+                    // (k, b, x) = (lane >> 4, (lane >> 2) & 3, lane & 3) supplies A = J[point k][4 b + x] and
+                    // B = J[point k][4 b' + x] and receives D[4 b + k'][4 b' + x] in lane (k', b, x) (layout:
+                    // tools/ubench/mfma4x4_layout). b' = b gives the four diagonal blocks, b' = b + 1 the blocks (0,1)
+                    // (1,2) (2,3) (3,0), b' = b + 2 the blocks (0,2) (1,3) and their transposes: every block of the
+                    // symmetric tile or its transpose. The A operand is the same (u, v) chunk the 16x16x4 form reads
+                    // (column c = lane & 15 of point k); the B operands are columns c + 4 and c + 8 of the same row.
                     // Five instructions per group of 4 points: (b,b) and (b,b+1) for the u rows and for the v rows, and
                     // ONE for the (b,b+2) blocks: slots b = 0, 1 take them for the u rows, slots b = 2, 3 -- whose
                     // (b,b+2) blocks are the transposes (2,0), (3,1) of the same two -- for the v rows. Its operands are
                     // 8-byte reads of the lane's own chunk and of chunk c + 8 at the u or the v half (jh, per lane).
+                    // 5 x 256 MACs per 4 points instead of 2 x 1024.
                     const int nfull = rows >= ROWS ? ROWS / 4 : rows >> 2;
                     const T2* src = slab + rowOff(k);                  // rows 4 s + k: + 66 chunks per group
                     const int c1 = (c + 4) & 15, c2 = (c + 8) & 15, jh = (lane >> 3) & 1;      // jh = 1: blocks 2, 3
