@@ -116,6 +116,7 @@ struct calib_handle_s {
     int schur_blocks = 1;
     int gram_wpi = 1;             // waves per gram item (two-kernel mode)
     int fused_wpi = 1;            // waves per item of the fused kernel
+    int gram_form = 0;            // fp64 fused kernel: 0 = chosen per shard, 1 = 16x16x4 tiles, 2 = 4x4x4 blocks (CALIB_GRAM_FORM)
     // LM rounds walk the points in chunks of whole views so that a chunk's compact J
     // (written by the jacobian kernel, read once by the gram kernel) can stay on-die
     struct Chunk { int64_t p0, p1; int item0, item1; };
@@ -352,7 +353,7 @@ int launch_fused_t(calib_handle_s* h, const LMState* st, int sel) {
     // fp64 items of more than two batches build J^T J from 4x4 blocks (v_mfma_f64_4x4x4_4b, symmetric half only;
     // c3 -4.5 %); shorter items stay on the 16x16x4 form, whose record goes to HBM straight from the accumulators
     // (one-batch items: c2 +4 % on the block form; two batches, c5: no difference)
-    const bool g44 = sizeof(T) == 8 && h->MN > (int64_t)128 * h->n_items;
+    const bool g44 = sizeof(T) == 8 && (h->gram_form == 2 || (h->gram_form == 0 && h->MN > (int64_t)128 * h->n_items));
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, h->stream, h->P[0].p,
                            h->P[1].p, reinterpret_cast<const T2*>(h->uv.p), reinterpret_cast<const T2*>(h->XY.p),
@@ -514,6 +515,7 @@ int calib_create(int model, int dtype, int device_id, calib_handle_t* out_handle
         }
     }
     if (const char* e = std::getenv("CALIB_LM_MODE")) h->lm_mode = std::atoi(e) ? CALIB_LM_TWO_KERNEL : CALIB_LM_FUSED;
+    if (const char* e = std::getenv("CALIB_GRAM_FORM")) h->gram_form = std::strcmp(e, "tile") == 0 ? 1 : (std::strcmp(e, "block") == 0 ? 2 : 0);
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0)

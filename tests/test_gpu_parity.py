@@ -104,7 +104,10 @@ def test_normal_equations_and_step(tag, name, model):
                                             ("g2_config1_fisheye.npz", "fisheye", orc.FISHEYE),
                                             ("g3_unittest15.npz", "radtan", orc.RADTAN),
                                             ("g4_realistic.npz", "radtan", orc.RADTAN)])
-def test_refine_matches_reference_result(tag, name, model):
+@pytest.mark.parametrize("form", ["tile", "block"])
+def test_refine_matches_reference_result(tag, name, model, form, monkeypatch):
+    # both forms of the fp64 fused kernel (J^T J from 16x16x4 tiles / from 4x4x4 blocks) against the reference's loop
+    monkeypatch.setenv("CALIB_GRAM_FORM", form)
     g = loadGolden(tag)
     P0 = g["P0"]
     eng = makeEngine(name, g)
@@ -342,8 +345,10 @@ def test_edge_cases():
         e.close()
 
 
-def test_one_big_view_spans_many_gram_items():
-    # a single view with 3000 points (> kGramChunk and > one tile) vs the oracle
+@pytest.mark.parametrize("form", ["tile", "block"])
+def test_one_big_view_spans_many_gram_items(form, monkeypatch):
+    # a single view with 3000 points (> kGramChunk and > one tile; several waves per item) vs the oracle
+    monkeypatch.setenv("CALIB_GRAM_FORM", form)
     rng = np.random.default_rng(5)
     corners = np.column_stack((rng.uniform(0, 0.4, 3000), rng.uniform(0, 0.3, 3000), rng.uniform(-0.01, 0.01, 3000)))
     g = loadGolden("g2_config1_radtan.npz")

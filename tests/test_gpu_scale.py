@@ -304,11 +304,13 @@ def test_c5_shape_single_shard_sample():
     eng.close()
 
 
-@pytest.mark.parametrize("name,model,seed", [("radtan", orc.RADTAN, 1), ("fisheye", orc.FISHEYE, 2), ("radtan", orc.RADTAN, 3)])
-def test_random_ragged_views_vs_c_oracle(name, model, seed):
+@pytest.mark.parametrize("name,model,seed,form", [("radtan", orc.RADTAN, 1, "tile"), ("fisheye", orc.FISHEYE, 2, "tile"),
+                                                  ("radtan", orc.RADTAN, 3, "block"), ("fisheye", orc.FISHEYE, 4, "block")])
+def test_random_ragged_views_vs_c_oracle(name, model, seed, form, monkeypatch):
     """Ragged problems with awkward sizes (3..700 points per view: below / at / above the 4-point
     group, the 64-lane batch, the 256-point tile and the 512-point item; general 3-D model points)
-    against the C oracle on the same inputs."""
+    against the C oracle on the same inputs, with J^T J built from 16x16x4 tiles and from 4x4x4 blocks."""
+    monkeypatch.setenv("CALIB_GRAM_FORM", form)
     from oracle import c_oracle
     if not c_oracle.available():
         pytest.skip("oracle/libcalib_oracle.so not built")
