@@ -208,6 +208,7 @@ def main():
     if args.steps > SEG:
         sys.exit(f"bench.py: --steps is at most {SEG} (lambda leaves the fp64 range in longer runs with the stop rule off)")
     allReduceKind = None
+    ranksSeen = 1
     if dist is not None:
         allReduce = None
         if args.allreduce in ("auto", "peer") and world > 1:
@@ -226,6 +227,10 @@ def main():
             allReduce = distributed.torchAllReduce(eng, torch.device("cuda", local))
             allReduceKind = "torch.distributed.all_reduce"
         lm = distributed.ShardedLM(eng, allReduce)
+        # how many ranks the process group really has (not WORLD_SIZE): every rank contributes a one
+        seen = torch.ones(1, dtype=torch.int32, device=torch.device("cuda", local) if args.backend == "nccl" else "cpu")
+        dist.all_reduce(seen)
+        ranksSeen = int(seen.item())
     state = {"P": shard["P0"], "iters": 0, "trace": [], "sse": float("nan")}
 
     def drain():
@@ -430,6 +435,9 @@ def main():
                                    f"{cfg['model']}, {cfg['dtype']}, sensor noise {args.noise} px",
                        "views_per_gpu": viewsPerGpu, "points_per_view": shard["pointsPerView"],
                        "global_points": MNglobal, "distortion": cfg["model"], "parallelism": f"views-sharded x{world}", "allreduce": allReduceKind,
+                       "ranks_seen": ranksSeen,
+                       "exchange_selftest": None if dist is None else ("torch.distributed.all_reduce needs none" if allReduceKind.startswith("torch")
+                                                                        else "exact sums of rank-dependent values over all ranks, against a deadline, passed on every rank"),
                        "lm_mode": args.lm_mode},
             "roofline": mainRoof,
             "roofline_jacobian_kernel": jacRoof,
