@@ -116,6 +116,7 @@ struct calib_handle_s {
     int schur_blocks = 1;
     int gram_wpi = 1;             // waves per gram item (two-kernel mode)
     int fused_wpi = 1;            // waves per item of the fused kernel
+    int uniform_n = 0;            // > 0: every item is one whole view of exactly this many points, in order (item i = view i = points [i n, (i+1) n))
     int gram_form = 0;            // fp64 fused kernel: 0 = chosen per shard, 1 = 16x16x4 tiles, 2 = 4x4x4 blocks (CALIB_GRAM_FORM)
     // LM rounds walk the points in chunks of whole views so that a chunk's compact J
     // (written by the jacobian kernel, read once by the gram kernel) can stay on-die
@@ -358,7 +359,7 @@ int launch_fused_t(calib_handle_s* h, const LMState* st, int sel) {
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, h->stream, h->P[0].p,
                            h->P[1].p, reinterpret_cast<const T2*>(h->uv.p), reinterpret_cast<const T2*>(h->XY.p),
                            reinterpret_cast<const T*>(h->Z.p), reinterpret_cast<const T*>(h->VC.p), h->item_pt0.p,
-                           h->item_n.p, h->item_view.p, h->n_items, wpi, h->emit_tab.p, st, sel, h->G[0].p, h->G[1].p,
+                           h->item_n.p, h->item_view.p, h->n_items, h->uniform_n, wpi, h->emit_tab.p, st, sel, h->G[0].p, h->G[1].p,
                            h->bpart.p);
     };
     if constexpr (sizeof(T) == 8) {
@@ -731,6 +732,13 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
         return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
     };
     HIP_TRY(upload(h->view_ext.p, view_ext.data(), view_ext.size() * 4));
+    {
+        // uniform shards (every view fully detected: the usual case) need no item tables in the fused kernel
+        int un = item_n.empty() ? 0 : item_n[0];
+        for (size_t i = 0; i < item_n.size() && un > 0; ++i)
+            if (item_n[i] != un || item_pt0[i] != (int64_t)i * un || item_view[i] != (int)i) un = 0;
+        h->uniform_n = un;
+    }
     HIP_TRY(upload(h->item_n.p, item_n.data(), item_n.size() * 4));
     HIP_TRY(upload(h->item_view.p, item_view.data(), item_view.size() * 4));
     HIP_TRY(upload(h->item_pt0.p, item_pt0.data(), item_pt0.size() * 8));

@@ -355,7 +355,8 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
                                                     const T* __restrict__ Z, const T* __restrict__ VC,
                                                     const int64_t* __restrict__ item_pt0,
                                                     const int* __restrict__ item_n,
-                                                    const int* __restrict__ item_view, int n_items, int wpi,
+                                                    const int* __restrict__ item_view, int n_items,
+                                                    int uniform_n, int wpi,
                                                     const uint32_t* __restrict__ emit_tab,
                                                     const LMState* __restrict__ st, int sel,
                                                     double* __restrict__ G0, double* __restrict__ G1,
@@ -401,12 +402,14 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
     // (u, v) the diagonal blocks (b, b), the blocks (b, b+1) and the blocks (b, b+2) of the 4 x 4 block grid
     double d0u = 0.0, d0v = 0.0, d1u = 0.0, d1v = 0.0, d2u = 0.0;
     if (valid) {
-        const int64_t pbeg = item_pt0[item];
-        const int n = item_n[item];
+        // uniform_n > 0 (item i = view i = points [i n, (i + 1) n)): the extent comes from the launch arguments and
+        // the first points are requested one memory latency earlier than through the item tables
+        const int64_t pbeg = uniform_n ? (int64_t)item * uniform_n : item_pt0[item];
+        const int n = uniform_n ? uniform_n : item_n[item];
         const int per = ((((n + 3) >> 2) + wpi - 1) >> lw) << 2;    // points per wave, multiple of 4
         const int qbeg = sub * per;
         const int qend = qbeg + per < n ? qbeg + per : n;
-        const T* vc = VC + (int64_t)__builtin_amdgcn_readfirstlane(item_view[item]) * kViewStride;
+        const T* vc = VC + (int64_t)__builtin_amdgcn_readfirstlane(uniform_n ? item : item_view[item]) * kViewStride;
         Shared<MODEL, T> sp;
         sp.load(P);
         // the constant columns of the slab rows: d(u,v)/duc = (1,0), d(u,v)/dvc = (0,1); for C == 16
