@@ -117,6 +117,7 @@ struct calib_handle_s {
     int gram_wpi = 1;             // waves per gram item (two-kernel mode)
     int fused_wpi = 1;            // waves per item of the fused kernel
     int uniform_n = 0;            // > 0: every item is one whole view of exactly this many points, in order (item i = view i = points [i n, (i+1) n))
+    int head_loads = 0;           // per-view kernels' record-head loads: 0 = by shard size, 1 = one load per value, 2 = coalesced + DPP (CALIB_HEAD_LOADS)
     int gram_form = 0;            // fp64 fused kernel: 0 = chosen per shard, 1 = 16x16x4 tiles, 2 = 4x4x4 blocks (CALIB_GRAM_FORM)
     // LM rounds walk the points in chunks of whole views so that a chunk's compact J
     // (written by the jacobian kernel, read once by the gram kernel) can stay on-die
@@ -398,16 +399,20 @@ PeerExchange next_exchange(calib_handle_s* h) {
     return x;
 }
 
+// shards above this many views load record heads in the coalesced, DPP-broadcast form (kernels.hpp: load_view_head)
+constexpr int kWideHeadViews = 40000;
+
 int launch_schur_reduce(calib_handle_s* h, const LMState* st, double* red) {
     const int VA = variantSize(h->L);
     if (h->nv > 0) {
         dim3 grid(h->schur_blocks, 3);
-        if (h->L == 10)
-            hipLaunchKernelGGL((schur_kernel<10>), grid, dim3(kSchurBlock), 0, h->stream, h->G[0].p,
-                               h->G[1].p, st, view_items(h), h->nv, h->bpart.p, h->n_bpart, h->part.p);
-        else
-            hipLaunchKernelGGL((schur_kernel<9>), grid, dim3(kSchurBlock), 0, h->stream, h->G[0].p,
-                               h->G[1].p, st, view_items(h), h->nv, h->bpart.p, h->n_bpart, h->part.p);
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, grid, dim3(kSchurBlock), 0, h->stream, h->G[0].p, h->G[1].p, st, view_items(h), h->nv,
+                               h->bpart.p, h->n_bpart, h->part.p);
+        };
+        const bool wide = h->head_loads == 2 || (h->head_loads == 0 && h->nv > kWideHeadViews);
+        if (h->L == 10) { if (wide) launch(schur_kernel<10, true>); else launch(schur_kernel<10, false>); }
+        else { if (wide) launch(schur_kernel<9, true>); else launch(schur_kernel<9, false>); }
         LAUNCHED(h, "schur_kernel");
     }
     hipLaunchKernelGGL(reduce_kernel, dim3(2 * VA), dim3(64), 0, h->stream, h->part.p,
@@ -437,9 +442,13 @@ int launch_update_backsub_t(calib_handle_s* h) {
     }
     const int per = kSchurThreads / 16;
     const int blocks = std::max(1, std::min(2048, (h->nv + per - 1) / per));     // grid-stride over views
-    hipLaunchKernelGGL((update_backsub_kernel<L, T>), dim3(blocks), dim3(kSchurThreads), 0, h->stream, h->G[0].p,
-                       h->G[1].p, st_cur(h), st_next(h), h->red, view_items(h), h->view_ext.p, h->nv,
-                       h->P[0].p, h->P[1].p, h->trace.p, reinterpret_cast<T*>(h->VC.p));
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kSchurThreads), 0, h->stream, h->G[0].p,
+                           h->G[1].p, st_cur(h), st_next(h), h->red, view_items(h), h->view_ext.p, h->nv,
+                           h->P[0].p, h->P[1].p, h->trace.p, reinterpret_cast<T*>(h->VC.p));
+    };
+    if (h->head_loads == 2 || (h->head_loads == 0 && h->nv > kWideHeadViews)) launch(update_backsub_kernel<L, T, true>);
+    else launch(update_backsub_kernel<L, T, false>);
     LAUNCHED(h, "update_backsub_kernel");
     return CALIB_OK;
 }
@@ -516,6 +525,7 @@ int calib_create(int model, int dtype, int device_id, calib_handle_t* out_handle
         }
     }
     if (const char* e = std::getenv("CALIB_LM_MODE")) h->lm_mode = std::atoi(e) ? CALIB_LM_TWO_KERNEL : CALIB_LM_FUSED;
+    if (const char* e = std::getenv("CALIB_HEAD_LOADS")) h->head_loads = std::strcmp(e, "narrow") == 0 ? 1 : (std::strcmp(e, "wide") == 0 ? 2 : 0);
     if (const char* e = std::getenv("CALIB_GRAM_FORM")) h->gram_form = std::strcmp(e, "tile") == 0 ? 1 : (std::strcmp(e, "block") == 0 ? 2 : 0);
     {
         int cus = 0;

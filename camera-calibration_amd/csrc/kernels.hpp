@@ -654,28 +654,64 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
     return r;
 }
 
+// lane N of every 16-lane DPP row to all lanes of that row (row_newbcast, gfx90a+)
+template <int N>
+__device__ __forceinline__ double row_bcast(double v) {
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + N, 0xf, 0xf, false),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + N, 0xf, 0xf, false));
+}
+
 // The head of a view's record(s) as the elimination wants it: V (lower triangle of the 6x6 view block,
-// the same for all 16 lanes: broadcast loads) and this lane's right-hand side b -- lane c < L: row c
-// of E (E[c][m] = R[m][c]); lanes >= L: the view gradient g_v.
-template <int L>
+// the same for all 16 lanes) and this lane's right-hand side b -- lane c < L: row c of E (E[c][m] = R[m][c]);
+// lanes >= L: the view gradient g_v. Two forms. WIDE (large shards, throughput-bound): lane c loads column c of
+// the six record rows and of the gradient row -- 7 loads of 128 contiguous bytes per view -- and the 21 + 6
+// values every lane needs from columns L..L+5 are broadcast inside the 16-lane group (DPP); c5 schur 61 -> 53 us.
+// Otherwise (latency-bound shards): one load per value, 27 per lane with 21 of them the same address in all 16
+// lanes -- more work for the address coalescer, but no chain of 54 DPP moves behind the loads (c3 / c4 -0.9 us).
+template <int L, bool WIDE>
 __device__ __forceinline__ void load_view_head(const double* __restrict__ G, int item0, int nitems, int c,
                                                double (&V)[21], double (&b)[6]) {
     const double* g = G + (int64_t)item0 * kGStride;
-    const int boff = c < L ? kGRows + c : kGg + L;            // + m * 16 (view rows) resp. + m (gradient)
-    const int bstep = c < L ? 16 : 1;
+    if constexpr (WIDE) {
+        double r[6], gv;
 #pragma unroll
-    for (int m = 0; m < 6; ++m) {
+        for (int m = 0; m < 6; ++m) r[m] = g[kGRows + m * 16 + c];
+        gv = g[kGg + c];
+        for (int it = 1; it < nitems; ++it) {                 // > 1 item only for views above kGramChunk points
+            g += kGStride;
 #pragma unroll
-        for (int n = 0; n <= m; ++n) V[tri(m, n)] = g[kGRows + m * 16 + L + n];
-        b[m] = g[boff + m * bstep];
-    }
-    for (int it = 1; it < nitems; ++it) {                     // > 1 item only for views above kGramChunk points
-        g += kGStride;
+            for (int m = 0; m < 6; ++m) r[m] += g[kGRows + m * 16 + c];
+            gv += g[kGg + c];
+        }
+        const double gg[6] = {row_bcast<L>(gv), row_bcast<L + 1>(gv), row_bcast<L + 2>(gv),
+                              row_bcast<L + 3>(gv), row_bcast<L + 4>(gv), row_bcast<L + 5>(gv)};
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+            V[tri(m, 0)] = row_bcast<L>(r[m]);
+            if (m >= 1) V[tri(m, 1)] = row_bcast<L + 1>(r[m]);
+            if (m >= 2) V[tri(m, 2)] = row_bcast<L + 2>(r[m]);
+            if (m >= 3) V[tri(m, 3)] = row_bcast<L + 3>(r[m]);
+            if (m >= 4) V[tri(m, 4)] = row_bcast<L + 4>(r[m]);
+            if (m >= 5) V[tri(m, 5)] = row_bcast<L + 5>(r[m]);
+            b[m] = c < L ? r[m] : gg[m];
+        }
+    } else {
+        const int boff = c < L ? kGRows + c : kGg + L;        // + m * 16 (view rows) resp. + m (gradient)
+        const int bstep = c < L ? 16 : 1;
 #pragma unroll
         for (int m = 0; m < 6; ++m) {
 #pragma unroll
-            for (int n = 0; n <= m; ++n) V[tri(m, n)] += g[kGRows + m * 16 + L + n];
-            b[m] += g[boff + m * bstep];
+            for (int n = 0; n <= m; ++n) V[tri(m, n)] = g[kGRows + m * 16 + L + n];
+            b[m] = g[boff + m * bstep];
+        }
+        for (int it = 1; it < nitems; ++it) {                 // > 1 item only for views above kGramChunk points
+            g += kGStride;
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+#pragma unroll
+                for (int n = 0; n <= m; ++n) V[tri(m, n)] += g[kGRows + m * 16 + L + n];
+                b[m] += g[boff + m * bstep];
+            }
         }
     }
 }
@@ -725,7 +761,7 @@ __device__ __forceinline__ bool eliminate(double (&V)[21], const double (&b)[6],
 constexpr int kSchurBlock = 256;
 constexpr int kSchurViewsPerBlock = kSchurBlock / 16;
 
-template <int L>
+template <int L, bool WIDE>
 __global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __restrict__ G0,
                                                             const double* __restrict__ G1,
                                                             const LMState* __restrict__ st,
@@ -776,7 +812,7 @@ __global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __r
     if (v0 + grp < nv) {
         // view_item0 == nullptr: every view is a single item (item index == view index)
         const int v = v0 + grp, i0 = view_item0 ? view_item0[v] : v;
-        load_view_head<L>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
+        load_view_head<L, WIDE>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
     }
     if (st->done) return;
     const bool boot = st->round == 0;
@@ -807,7 +843,7 @@ __global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __r
         v0 += gridDim.x * kSchurViewsPerBlock;
         if (v0 + grp < nv) {                                  // the next trip's heads, behind this trip's MFMAs
             const int v = v0 + grp, i0 = view_item0 ? view_item0[v] : v;
-            load_view_head<L>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
+            load_view_head<L, WIDE>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
         }
         // W^T W: K-slot k = this lane's view, six rows per view
 #pragma unroll
@@ -1284,7 +1320,7 @@ __device__ __forceinline__ void finish_view(const double (&V)[21], const double 
     if (c < 2) dst[16 + c] = (T)(c == 0 ? o18[16] : o18[17]);
 }
 
-template <int L, typename T>
+template <int L, typename T, bool WIDE>
 __global__ __launch_bounds__(kSchurThreads, 4) void update_backsub_kernel(
         const double* __restrict__ G0, const double* __restrict__ G1, const LMState* __restrict__ st_in,
         LMState* __restrict__ st_out, const double* __restrict__ red, const int* __restrict__ view_item0,
@@ -1319,7 +1355,7 @@ __global__ __launch_bounds__(kSchurThreads, 4) void update_backsub_kernel(
     for (int v = blockIdx.x * (kSchurThreads / 16) + (tid >> 4); v < nv; v += gridDim.x * (kSchurThreads / 16)) {
         double V[21], b[6], invd[6], z[6];
         const int i0 = view_item0 ? view_item0[v] : v;
-        load_view_head<L>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
+        load_view_head<L, WIDE>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
         eliminate(V, b, lam, invd, z);
         finish_view<L, T>(V, invd, z, coef, c, v, view_ext, Pc, Pn, VC);
     }
@@ -1376,7 +1412,7 @@ __global__ __launch_bounds__(kUpdThreads) void update_backsub_small_kernel(
         }
         if (v < nv) {
             const int i0 = view_item0 ? view_item0[v] : v;
-            load_view_head<L>(cur ? G1 : G0, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
+            load_view_head<L, false>(cur ? G1 : G0, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
             eliminate(V, b, lam, invd, z);
         }
     }

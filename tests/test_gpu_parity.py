@@ -370,6 +370,25 @@ def test_one_big_view_spans_many_gram_items(form, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("tag,name", [("g3_unittest15.npz", "radtan"), ("g2_config1_fisheye.npz", "fisheye"),
+                                      ("g5_ragged200.npz", "radtan")])
+def test_record_head_load_forms_are_bitwise_equal(tag, name, monkeypatch):
+    """The per-view kernels read a view's record head either value by value or as seven coalesced rows handed round
+    by DPP (large shards): same values, same arithmetic -- the whole LM run must come out bit for bit the same."""
+    g = loadGolden(tag)
+    out = {}
+    for form in ("narrow", "wide"):
+        monkeypatch.setenv("CALIB_HEAD_LOADS", form)
+        eng = makeEngine(name, g)
+        d = eng.stepDelta(g["P0"], 1e-3)
+        sse, P, iters, trace = eng.refine(g["P0"], 40)
+        out[form] = (d, sse, P, iters, trace)
+        eng.close()
+    a, b = out["narrow"], out["wide"]
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2])
+    assert a[3] == b[3] and np.array_equal(a[4], b[4])
+
+
 @pytest.mark.parametrize("tag,name", [("g3_unittest15.npz", "radtan"), ("g2_config1_fisheye.npz", "fisheye")])
 def test_fused_and_two_kernel_modes_agree(tag, name):
     """CALIB_LM_FUSED (J stays on the CU) and CALIB_LM_TWO_KERNEL (compact J through HBM) build the
