@@ -668,33 +668,46 @@ __device__ __forceinline__ double row_bcast(double v) {
 // values every lane needs from columns L..L+5 are broadcast inside the 16-lane group (DPP); c5 schur 61 -> 53 us.
 // Otherwise (latency-bound shards): one load per value, 27 per lane with 21 of them the same address in all 16
 // lanes -- more work for the address coalescer, but no chain of 54 DPP moves behind the loads (c3 / c4 -0.9 us).
+// WIDE form in two steps, so that a kernel can have the next view's rows in flight while it factors this one:
+// the raw column-c elements of the six rows and of the gradient row (summed over the view's items) ...
+__device__ __forceinline__ void request_head_rows(const double* __restrict__ G, int item0, int nitems, int c,
+                                                  double (&r)[7]) {
+    const double* g = G + (int64_t)item0 * kGStride;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) r[m] = g[kGRows + m * 16 + c];
+    r[6] = g[kGg + c];
+    for (int it = 1; it < nitems; ++it) {                     // > 1 item only for views above kGramChunk points
+        g += kGStride;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) r[m] += g[kGRows + m * 16 + c];
+        r[6] += g[kGg + c];
+    }
+}
+// ... and their expansion into V and b by broadcasts inside the 16-lane group
+template <int L>
+__device__ __forceinline__ void expand_head_rows(const double (&r)[7], int c, double (&V)[21], double (&b)[6]) {
+    const double gg[6] = {row_bcast<L>(r[6]), row_bcast<L + 1>(r[6]), row_bcast<L + 2>(r[6]),
+                          row_bcast<L + 3>(r[6]), row_bcast<L + 4>(r[6]), row_bcast<L + 5>(r[6])};
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+        V[tri(m, 0)] = row_bcast<L>(r[m]);
+        if (m >= 1) V[tri(m, 1)] = row_bcast<L + 1>(r[m]);
+        if (m >= 2) V[tri(m, 2)] = row_bcast<L + 2>(r[m]);
+        if (m >= 3) V[tri(m, 3)] = row_bcast<L + 3>(r[m]);
+        if (m >= 4) V[tri(m, 4)] = row_bcast<L + 4>(r[m]);
+        if (m >= 5) V[tri(m, 5)] = row_bcast<L + 5>(r[m]);
+        b[m] = c < L ? r[m] : gg[m];
+    }
+}
+
 template <int L, bool WIDE>
 __device__ __forceinline__ void load_view_head(const double* __restrict__ G, int item0, int nitems, int c,
                                                double (&V)[21], double (&b)[6]) {
     const double* g = G + (int64_t)item0 * kGStride;
     if constexpr (WIDE) {
-        double r[6], gv;
-#pragma unroll
-        for (int m = 0; m < 6; ++m) r[m] = g[kGRows + m * 16 + c];
-        gv = g[kGg + c];
-        for (int it = 1; it < nitems; ++it) {                 // > 1 item only for views above kGramChunk points
-            g += kGStride;
-#pragma unroll
-            for (int m = 0; m < 6; ++m) r[m] += g[kGRows + m * 16 + c];
-            gv += g[kGg + c];
-        }
-        const double gg[6] = {row_bcast<L>(gv), row_bcast<L + 1>(gv), row_bcast<L + 2>(gv),
-                              row_bcast<L + 3>(gv), row_bcast<L + 4>(gv), row_bcast<L + 5>(gv)};
-#pragma unroll
-        for (int m = 0; m < 6; ++m) {
-            V[tri(m, 0)] = row_bcast<L>(r[m]);
-            if (m >= 1) V[tri(m, 1)] = row_bcast<L + 1>(r[m]);
-            if (m >= 2) V[tri(m, 2)] = row_bcast<L + 2>(r[m]);
-            if (m >= 3) V[tri(m, 3)] = row_bcast<L + 3>(r[m]);
-            if (m >= 4) V[tri(m, 4)] = row_bcast<L + 4>(r[m]);
-            if (m >= 5) V[tri(m, 5)] = row_bcast<L + 5>(r[m]);
-            b[m] = c < L ? r[m] : gg[m];
-        }
+        double r[7];
+        request_head_rows(G, item0, nitems, c, r);
+        expand_head_rows<L>(r, c, V, b);
     } else {
         const int boff = c < L ? kGRows + c : kGg + L;        // + m * 16 (view rows) resp. + m (gradient)
         const int bstep = c < L ? 16 : 1;
@@ -827,11 +840,19 @@ __global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __r
 
     d4 acc = {0.0, 0.0, 0.0, 0.0};
     double nfail = 0.0;
+    const int stride = gridDim.x * kSchurViewsPerBlock;
     while (v0 < nv) {
         double z[6];
 #pragma unroll
         for (int m = 0; m < 6; ++m) z[m] = 0.0;
-        if (v0 + grp < nv) {                                  // whole 16-lane group together
+        const bool live = v0 + grp < nv;                      // whole 16-lane group together
+        const bool more = v0 + stride + grp < nv;
+        double rn[7];
+        if (WIDE && more) {                                   // the next trip's seven rows: in flight during this elimination
+            const int v = v0 + stride + grp, i0 = view_item0 ? view_item0[v] : v;
+            request_head_rows(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, rn);
+        }
+        if (live) {
             double invd[6];
             const bool ok = eliminate(V, b, lam, invd, z);
             if (c > L) {                                      // lanes above the gradient column contribute nothing
@@ -840,10 +861,14 @@ __global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __r
             }
             if (!ok) nfail += 1.0;
         }
-        v0 += gridDim.x * kSchurViewsPerBlock;
-        if (v0 + grp < nv) {                                  // the next trip's heads, behind this trip's MFMAs
-            const int v = v0 + grp, i0 = view_item0 ? view_item0[v] : v;
-            load_view_head<L, WIDE>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
+        v0 += stride;
+        if (more) {
+            if constexpr (WIDE) {
+                expand_head_rows<L>(rn, c, V, b);
+            } else {                                          // the next trip's heads, behind this trip's MFMAs
+                const int v = v0 + grp, i0 = view_item0 ? view_item0[v] : v;
+                load_view_head<L, false>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
+            }
         }
         // W^T W: K-slot k = this lane's view, six rows per view
 #pragma unroll
@@ -1352,10 +1377,25 @@ __global__ __launch_bounds__(kSchurThreads, 4) void update_backsub_kernel(
     const double* Pc = cur ? P1 : P0;
     double* Pn = cur ? P0 : P1;
     // grid-stride over views: the decision / solve above is paid once per workgroup, not per view
-    for (int v = blockIdx.x * (kSchurThreads / 16) + (tid >> 4); v < nv; v += gridDim.x * (kSchurThreads / 16)) {
-        double V[21], b[6], invd[6], z[6];
+    const int stride = gridDim.x * (kSchurThreads / 16);
+    int v = blockIdx.x * (kSchurThreads / 16) + (tid >> 4);
+    double rn[7];
+    if (WIDE && v < nv) {
         const int i0 = view_item0 ? view_item0[v] : v;
-        load_view_head<L, WIDE>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
+        request_head_rows(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, rn);
+    }
+    for (; v < nv; v += stride) {
+        double V[21], b[6], invd[6], z[6];
+        if constexpr (WIDE) {
+            expand_head_rows<L>(rn, c, V, b);
+            if (v + stride < nv) {                            // the next view's rows: in flight during this view's update
+                const int vn = v + stride, i0 = view_item0 ? view_item0[vn] : vn;
+                request_head_rows(G, i0, view_item0 ? view_item0[vn + 1] - i0 : 1, c, rn);
+            }
+        } else {
+            const int i0 = view_item0 ? view_item0[v] : v;
+            load_view_head<L, false>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
+        }
         eliminate(V, b, lam, invd, z);
         finish_view<L, T>(V, invd, z, coef, c, v, view_ext, Pc, Pn, VC);
     }
