@@ -274,8 +274,29 @@ __global__ __launch_bounds__(256) void gram_kernel(const typename Pair<T>::type*
         const int64_t ge = gb + per < grp1 ? gb + per : grp1;
         const int chunk = lane < 4 * C ? lane : 4 * C - 1;
         const int srcLane = 4 * cc + k;
+        d4 accv = {0.0, 0.0, 0.0, 0.0};                      // v rows: a second, independent MFMA chain
         for (int64_t g = gb; g < ge; g += kGramUnroll) {
             T2 raw[kGramUnroll], rv[kGramUnroll];
+            // wave-uniform: every point of these groups belongs to the item -- no masks, no 64-bit index selects
+            // (the masked form below spends ~50 vector instructions per group, this one ~12)
+            if (4 * g >= pbeg && 4 * (g + kGramUnroll) <= pend && g + kGramUnroll <= ge) {
+                const T2* Jg = J + g * (4 * C) + chunk;
+                const T2* rg = rq + 4 * g + k;
+#pragma unroll
+                for (int u = 0; u < kGramUnroll; ++u) { raw[u] = Jg[u * 4 * C]; rv[u] = rg[4 * u]; }
+#pragma unroll
+                for (int u = 0; u < kGramUnroll; ++u) {
+                    const T2 jv = lane_gather(raw[u], srcLane);
+                    const double rx = (double)rv[u].x, ry = (double)rv[u].y;
+                    const double jx = (C == 16 || cvalid) ? (double)jv.x : 0.0;
+                    const double jy = (C == 16 || cvalid) ? (double)jv.y : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jx, jx, acc, 0, 0, 0);
+                    accv = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, accv, 0, 0, 0);
+                    gacc += jx * rx + jy * ry;
+                    eacc += rx * rx + ry * ry;
+                }
+                continue;
+            }
             bool pv[kGramUnroll];
 #pragma unroll
             for (int u = 0; u < kGramUnroll; ++u) {
@@ -293,11 +314,13 @@ __global__ __launch_bounds__(256) void gram_kernel(const typename Pair<T>::type*
                 const double jx = (ok && cvalid) ? (double)jv.x : 0.0;
                 const double jy = (ok && cvalid) ? (double)jv.y : 0.0;
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jx, jx, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, acc, 0, 0, 0);
+                accv = __builtin_amdgcn_mfma_f64_16x16x4f64(jy, jy, accv, 0, 0, 0);
                 gacc += jx * rx + jy * ry;
                 eacc += rx * rx + ry * ry;
             }
         }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) acc[reg] += accv[reg];
         gacc += __shfl_xor(gacc, 16, 64);
         gacc += __shfl_xor(gacc, 32, 64);
         eacc += __shfl_xor(eacc, 16, 64);
