@@ -141,6 +141,7 @@ struct calib_handle_s {
     void* peer_mem = nullptr;             // this rank's slot memory (uncached / fine-grained device memory)
     std::vector<void*> peer_open;         // IPC mappings of the other ranks' slot memory
     DevBuf<unsigned long long*> peer_slots;
+    std::vector<unsigned long long*> peer_slot_host;     // the same pointers, for the kernel arguments
     DevBuf<int> peer_flags;               // [0] a spin timed out, [1] self-test mismatches
     int peer_world = 0, peer_rank = 0;
     unsigned peer_epoch = 0;
@@ -391,6 +392,7 @@ const int* view_items(const calib_handle_s* h) { return h->n_items == h->nv ? nu
 PeerExchange next_exchange(calib_handle_s* h) {
     PeerExchange x;
     x.slots = h->peer_slots.p;
+    for (int r = 0; r < kPeerInline; ++r) x.slot8[r] = r < (int)h->peer_slot_host.size() ? h->peer_slot_host[(size_t)r] : nullptr;
     x.fault = h->peer_flags.p;
     x.timeout_ticks = (unsigned long long)(h->peer_timeout_s * 1e8);      // wall_clock64 counts at 100 MHz
     x.epoch = ++h->peer_epoch;
@@ -417,7 +419,7 @@ int launch_schur_reduce(calib_handle_s* h, const LMState* st, double* red) {
     }
     hipLaunchKernelGGL(reduce_kernel, dim3(2 * VA), dim3(64), 0, h->stream, h->part.p,
                        h->nv > 0 ? h->schur_blocks : 0, VA, st, red,
-                       h->exchange_round ? next_exchange(h) : PeerExchange{nullptr, nullptr, 0, 0, 0, 0});
+                       h->exchange_round ? next_exchange(h) : PeerExchange{});
     LAUNCHED(h, "reduce_kernel");
     return CALIB_OK;
 }
@@ -555,6 +557,7 @@ void peer_release(calib_handle_s* h) {
     if (h->peer_mem) (void)hipFree(h->peer_mem);
     h->peer_mem = nullptr;
     h->peer_slots.release();
+    h->peer_slot_host.clear();
     h->peer_flags.release();
     h->peer_connected = false;
     h->peer_world = 0;
@@ -1218,6 +1221,7 @@ int calib_peer_connect(calib_handle_t h, const void* handles, double timeout_s) 
         h->peer_open[(size_t)r] = m;
         slots[(size_t)r] = static_cast<unsigned long long*>(m);
     }
+    h->peer_slot_host = slots;
     HIP_TRY(h->peer_slots.alloc((size_t)n));
     HIP_TRY(h->peer_flags.alloc(2));
     HIP_TRY(hipMemcpy(h->peer_slots.p, slots.data(), (size_t)n * sizeof(slots[0]), hipMemcpyHostToDevice));

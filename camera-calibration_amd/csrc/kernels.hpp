@@ -941,8 +941,11 @@ __global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __r
 constexpr int kPeerStride = 448;       // >= reduceSize(10) = 444 cells per (source, parity)
 constexpr int kPeerMaxRanks = 64;      // one lane per rank
 
+constexpr int kPeerInline = 8;         // ranks whose slot pointers travel in the kernel arguments
+
 struct PeerExchange {
     unsigned long long* const* slots;  // [world] rank d's slot memory as mapped on this device (device array)
+    unsigned long long* slot8[kPeerInline];  // the first 8 of them by value: no dependent load before the stores
     int* fault;
     unsigned long long timeout_ticks;
     unsigned epoch;                    // > 0, +1 per exchange; identical on every rank
@@ -966,12 +969,23 @@ __device__ __forceinline__ double peer_sum(const PeerExchange& x, int i, double 
     const unsigned par = x.epoch & 1u;
     double v = 0.0;
     if (lane < x.world) {
-        unsigned long long* dst = x.slots[lane] + 2 * ((int64_t)(x.rank * 2 + par) * kPeerStride + i);
+        unsigned long long* base = nullptr, * own = nullptr;
+        if (x.world <= kPeerInline) {
+#pragma unroll
+            for (int r = 0; r < kPeerInline; ++r) {
+                base = lane == r ? x.slot8[r] : base;
+                own = x.rank == r ? x.slot8[r] : own;
+            }
+        } else {
+            base = x.slots[lane];
+            own = x.slots[x.rank];
+        }
+        unsigned long long* dst = base + 2 * ((int64_t)(x.rank * 2 + par) * kPeerStride + i);
         u32x4 mine;
         mine.x = (unsigned)__double2loint(t); mine.y = x.epoch;
         mine.z = (unsigned)__double2hiint(t); mine.w = x.epoch;
         cell_store(dst, mine);
-        const unsigned long long* src = x.slots[x.rank] + 2 * ((int64_t)(lane * 2 + par) * kPeerStride + i);
+        const unsigned long long* src = own + 2 * ((int64_t)(lane * 2 + par) * kPeerStride + i);
         const long long t0 = wall_clock64();
         for (;;) {
             const u32x4 c = cell_load(src);
