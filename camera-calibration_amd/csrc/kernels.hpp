@@ -931,9 +931,9 @@ __global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __r
 // contributed by rank src in a round of that parity. A cell is two 8-byte words {data half, epoch}: an 8-byte
 // word is never torn, so a reader that sees the round's epoch in a word also sees that word's data (the
 // "LL" idea of the collective libraries) -- the writer needs no release fence and no separate flag. A wave
-// that has summed element i stores it into cell (rank, parity, i) of EVERY rank (lane d writes to rank d,
-// point-to-point over xGMI, its own memory included), then lane s polls cell (s, parity, i) of its own
-// memory until rank s's epoch shows up; the values are added in rank order, so every rank gets bitwise the
+// that has summed element i stores it into cell (rank, parity, i) of every OTHER rank (lane d writes to rank d,
+// point-to-point over xGMI), then lane s polls cell (s, parity, i) of its own memory until rank s's epoch
+// shows up (its own contribution it takes from the register); the values are added in rank order, so every rank gets bitwise the
 // same sums. Two parities are enough: a rank can only start writing round r + 2 after it has received
 // everybody's round r + 1, which they sent after reading round r.
 // Every spin is bounded by the wall clock (100 MHz): on a timeout the fault word is raised, the element
@@ -984,10 +984,11 @@ __device__ __forceinline__ double peer_sum(const PeerExchange& x, int i, double 
         u32x4 mine;
         mine.x = (unsigned)__double2loint(t); mine.y = x.epoch;
         mine.z = (unsigned)__double2hiint(t); mine.w = x.epoch;
-        cell_store(dst, mine);
+        if (lane != x.rank) cell_store(dst, mine);               // this rank's own contribution stays in its register
         const unsigned long long* src = own + 2 * ((int64_t)(lane * 2 + par) * kPeerStride + i);
         const long long t0 = wall_clock64();
-        for (;;) {
+        v = t;
+        while (lane != x.rank) {
             const u32x4 c = cell_load(src);
             if (c.y == x.epoch && c.w == x.epoch) {
                 v = __hiloint2double((int)c.z, (int)c.x);

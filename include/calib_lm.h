@@ -154,7 +154,7 @@ int calib_lm_run_sharded(calib_handle_t h, int rounds, int check_every);
 
 /* ---- peer exchange over xGMI (optional; the fastest form of the one exchange) -----------------------
  * The sum over the ranks happens INSIDE the kernel that finishes a shard's reduce buffer: each wave stores its
- * element point-to-point into every rank's slot memory and polls its own for the others' (kernels.hpp,
+ * element point-to-point into every other rank's slot memory and polls its own for theirs (kernels.hpp,
  * "peer exchange"); no collective is launched, no stream is handed over, and every rank adds in rank order,
  * so the reduced system -- hence every accept/reject decision -- is bitwise identical everywhere. It replaces
  * the all-reduce torch.distributed / RCCL would launch per LM round. One process per GPU, ranks on one node:
