@@ -118,6 +118,7 @@ struct calib_handle_s {
     int fused_wpi = 1;            // waves per item of the fused kernel
     int uniform_n = 0;            // > 0: every item is one whole view of exactly this many points, in order (item i = view i = points [i n, (i+1) n))
     int head_loads = 0;           // per-view kernels' record-head loads: 0 = by shard size, 1 = one load per value, 2 = coalesced + DPP (CALIB_HEAD_LOADS)
+    int items_per_wave = 0;       // fused kernel, short uniform items: 0 = chosen per shard (CALIB_ITEMS_PER_WAVE)
     int gram_form = 0;            // fp64 fused kernel: 0 = chosen per shard, 1 = 16x16x4 tiles, 2 = 4x4x4 blocks (CALIB_GRAM_FORM)
     // LM rounds walk the points in chunks of whole views so that a chunk's compact J
     // (written by the jacobian kernel, read once by the gram kernel) can stay on-die
@@ -350,25 +351,35 @@ int launch_fused_t(calib_handle_s* h, const LMState* st, int sel) {
     if (h->n_items == 0) return CALIB_OK;
     // ROWS = 32, 4 waves per workgroup: the 64-row / 2-wave variants measured 1-6 % slower (c3, c5, c2)
     const int wpi = std::min(h->fused_wpi, 4);
-    const int ipb = 4 / wpi;
+    const bool g44 = sizeof(T) == 8 && (h->gram_form == 2 || (h->gram_form == 0 && h->MN > (int64_t)128 * h->n_items));
+    // short uniform items (tile forms, one wave each): on shards large enough to leave every workgroup slot of the
+    // chip (4 per CU) four workgroups even so, a wave takes up to four items in a row -- one prologue, one partial,
+    // one barrier, the next item's points requested early (c5 shard -7 %; c4's 12 500 items: no gain, c2: slower)
+    int ipw = 1;
+    if (!g44 && wpi == 1 && h->uniform_n > 0) {
+        if (h->items_per_wave > 0) ipw = h->items_per_wave;
+        else while (ipw < 4 && h->n_items / (8 * ipw) >= 16 * h->num_cus) ipw *= 2;
+    }
+    const int ipb = (4 / wpi) * ipw;
     const int blocks = (h->n_items + ipb - 1) / ipb;
     int pi = prof_begin(h, 2);
     // fp64 items of more than two batches build J^T J from 4x4 blocks (v_mfma_f64_4x4x4_4b, symmetric half only;
     // c3 -4.5 %); shorter items stay on the 16x16x4 form, whose record goes to HBM straight from the accumulators
     // (one-batch items: c2 +4 % on the block form; two batches, c5: no difference)
-    const bool g44 = sizeof(T) == 8 && (h->gram_form == 2 || (h->gram_form == 0 && h->MN > (int64_t)128 * h->n_items));
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, h->stream, h->P[0].p,
                            h->P[1].p, reinterpret_cast<const T2*>(h->uv.p), reinterpret_cast<const T2*>(h->XY.p),
                            reinterpret_cast<const T*>(h->Z.p), reinterpret_cast<const T*>(h->VC.p), h->item_pt0.p,
-                           h->item_n.p, h->item_view.p, h->n_items, h->uniform_n, wpi, h->emit_tab.p, st, sel, h->G[0].p, h->G[1].p,
+                           h->item_n.p, h->item_view.p, h->n_items, h->uniform_n, ipw, wpi, h->emit_tab.p, st, sel, h->G[0].p, h->G[1].p,
                            h->bpart.p);
     };
     if constexpr (sizeof(T) == 8) {
-        if (g44) launch(fused_kernel<MODEL, T, 32, 4, true>);
-        else launch(fused_kernel<MODEL, T, 32, 4, false>);
+        if (g44) launch(fused_kernel<MODEL, T, 32, 4, true, false>);
+        else if (ipw > 1) launch(fused_kernel<MODEL, T, 32, 4, false, true>);
+        else launch(fused_kernel<MODEL, T, 32, 4, false, false>);
     } else {
-        launch(fused_kernel<MODEL, T, 32, 4, false>);
+        if (ipw > 1) launch(fused_kernel<MODEL, T, 32, 4, false, true>);
+        else launch(fused_kernel<MODEL, T, 32, 4, false, false>);
     }
     prof_end(h, pi);
     h->n_bpart = blocks;
@@ -528,6 +539,7 @@ int calib_create(int model, int dtype, int device_id, calib_handle_t* out_handle
     }
     if (const char* e = std::getenv("CALIB_LM_MODE")) h->lm_mode = std::atoi(e) ? CALIB_LM_TWO_KERNEL : CALIB_LM_FUSED;
     if (const char* e = std::getenv("CALIB_HEAD_LOADS")) h->head_loads = std::strcmp(e, "narrow") == 0 ? 1 : (std::strcmp(e, "wide") == 0 ? 2 : 0);
+    if (const char* e = std::getenv("CALIB_ITEMS_PER_WAVE")) h->items_per_wave = std::max(0, std::min(16, std::atoi(e)));
     if (const char* e = std::getenv("CALIB_GRAM_FORM")) h->gram_form = std::strcmp(e, "tile") == 0 ? 1 : (std::strcmp(e, "block") == 0 ? 2 : 0);
     {
         int cus = 0;

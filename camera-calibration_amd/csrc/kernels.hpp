@@ -371,7 +371,7 @@ constexpr int kFusedRowChunks = 17;                       // 16 columns + 1 pad 
 
 // ROWS = points transposed per LDS pass (32: two passes per 64-point batch, half the lanes
 // writing each time; 64: one pass, twice the LDS). WAVES = waves per workgroup.
-template <int MODEL, typename T, int ROWS, int WAVES, bool G44>
+template <int MODEL, typename T, int ROWS, int WAVES, bool G44, bool MULTI>
 __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) void fused_kernel(const double* __restrict__ P0, const double* __restrict__ P1,
                                                     const typename Pair<T>::type* __restrict__ uv,
                                                     const typename Pair<T>::type* __restrict__ XY,
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
                                                     const int64_t* __restrict__ item_pt0,
                                                     const int* __restrict__ item_n,
                                                     const int* __restrict__ item_view, int n_items,
-                                                    int uniform_n, int wpi,
+                                                    int uniform_n, int ipw, int wpi,
                                                     const uint32_t* __restrict__ emit_tab,
                                                     const LMState* __restrict__ st, int sel,
                                                     double* __restrict__ G0, double* __restrict__ G1,
@@ -411,8 +411,13 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lw = wpi == 4 ? 2 : (wpi == 2 ? 1 : 0);           // wpi is 1, 2 or 4: shifts, not divisions
     const int sub = wave & (wpi - 1);
-    const int item = blockIdx.x * (WAVES >> lw) + (wave >> lw);
-    const bool valid = item < n_items;
+    // ipw > 1 (host: uniform single-wave items of the tile forms only): the wave works through ipw consecutive
+    // items -- one prologue, one workgroup partial and one barrier for all of them, the next item's first points
+    // requested during this item's last batch; the shared part of the tiles keeps accumulating across the items
+    static_assert(!(G44 && MULTI), "multi-item waves exist for the tile forms only");
+    const int item_first = MULTI ? (blockIdx.x * WAVES + wave) * ipw : blockIdx.x * (WAVES >> lw) + (wave >> lw);
+    const bool valid = item_first < n_items;
+    int item = item_first;
     const int c = lane & 15, k = lane >> 4;
     // Lane l evaluates point sl(l) of its batch and stores row sl(l): inside each 16-lane block lanes 0-7 take the
     // even rows, lanes 8-15 the odd ones. A ds_write_b128 is served 8 consecutive lanes at a time; their rows
@@ -424,15 +429,45 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
     // fp64: the Gram is built from 4x4 blocks by v_mfma_f64_4x4x4_4b (see the contraction below): per row kind
     // (u, v) the diagonal blocks (b, b), the blocks (b, b+1) and the blocks (b, b+2) of the 4 x 4 block grid
     double d0u = 0.0, d0v = 0.0, d1u = 0.0, d1v = 0.0, d2u = 0.0;
+    double* Gbase = sel ? ((st->cur ^ 1) ? G1 : G0) : G0;
+    // One wave per item (tile forms): the item's record goes to HBM straight from the accumulators (lane (k, c) holds
+    // rows k + 4 reg -- 4 k + reg behind the fp32 MFMA -- of column c; 16 lanes store 128 contiguous bytes): rows
+    // L..L+5 of J^T J, then J^T r and sum r^2 from the residual's row. No table, no LDS, nothing to wait for.
+    auto emitDirect = [&](int it) {
+        constexpr int L = C - 6, RESROW = RCOL ? 15 : 4;
+        double* G = Gbase + (int64_t)it * kGStride;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = MF32 ? 4 * k + reg : k + 4 * reg;
+            double val = acc[reg] + acc2[reg];
+            if (ONES) {
+                // radtan: the u-tile's / v-tile's column 3 is the true column 3 / 4 (sum Ju / sum Jv, see above)
+                const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(acc2[reg]), 0x111, 0xf, 0xf, false);
+                const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(acc2[reg]), 0x111, 0xf, 0xf, false);
+                const double fromLeft = __hiloint2double(hi, lo);       // row_shr:1: lane c <- lane c - 1
+                val = c == 3 ? acc[reg] : (c == 4 ? fromLeft : val);
+            }
+            if (row >= L && row < L + 6) {
+                G[kGRows + (row - L) * 16 + c] = (RCOL && c == 15) ? 0.0 : val;
+            } else if (row == RESROW) {
+                if (RCOL) {
+                    G[c == 15 ? kGSse : kGg + c] = val;
+                } else {
+                    G[kGg + c] = val;
+                    if (c == 4) G[kGSse] = acc[reg] + acc2[reg];
+                }
+            }
+        }
+    };
     if (valid) {
         // uniform_n > 0 (item i = view i = points [i n, (i + 1) n)): the extent comes from the launch arguments and
         // the first points are requested one memory latency earlier than through the item tables
-        const int64_t pbeg = uniform_n ? (int64_t)item * uniform_n : item_pt0[item];
+        int64_t pbeg = uniform_n ? (int64_t)item * uniform_n : item_pt0[item];
         const int n = uniform_n ? uniform_n : item_n[item];
+        const int item_last = MULTI ? (item_first + ipw < n_items ? item_first + ipw : n_items) - 1 : item_first;
         const int per = ((((n + 3) >> 2) + wpi - 1) >> lw) << 2;    // points per wave, multiple of 4
         const int qbeg = sub * per;
         const int qend = qbeg + per < n ? qbeg + per : n;
-        const T* vc = VC + (int64_t)__builtin_amdgcn_readfirstlane(uniform_n ? item : item_view[item]) * kViewStride;
         Shared<MODEL, T> sp;
         sp.load(P);
         // the constant columns of the slab rows: d(u,v)/duc = (1,0), d(u,v)/dvc = (0,1); for C == 16
@@ -452,12 +487,17 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
         int64_t pn = pbeg + (qbeg + sl < qend ? qbeg + sl : qend - 1);
         T2 m_n = uv[pn], xy_n = XY[pn];
         T z_n = Z[pn];
+        for (;; ++item) {
+        const T* vc = VC + (int64_t)__builtin_amdgcn_readfirstlane(uniform_n ? item : item_view[item]) * kViewStride;
         for (int q0 = qbeg; q0 < qend; q0 += 64) {
             const int q = q0 + sl;
             const T2 m = m_n, xy = xy_n;
             const T z = z_n;
             if (q0 + 64 < qend) {
                 pn = pbeg + (q + 64 < qend ? q + 64 : qend - 1);
+                m_n = uv[pn]; xy_n = XY[pn]; z_n = Z[pn];
+            } else if (MULTI && item < item_last) {           // the next item's first batch (uniform items: qbeg = 0)
+                pn = pbeg + n + (sl < n ? sl : n - 1);
                 m_n = uv[pn]; xy_n = XY[pn]; z_n = Z[pn];
             }
             T u, v;
@@ -574,6 +614,22 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
                 }
             }
         }
+        if (!MULTI || item >= item_last) break;
+        // more items for this wave: this one's record leaves now, then everything that belongs to its view -- rows
+        // and columns L..L+5 of both tiles -- starts again from zero; the shared block, g_c and sum r^2 go on
+        emitDirect(item);
+        {
+            constexpr int L = C - 6;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = MF32 ? 4 * k + reg : k + 4 * reg;
+                const bool ofView = (row >= L && row < L + 6) || (c >= L && c < L + 6);
+                acc[reg] = ofView ? 0.0 : acc[reg];
+                acc2[reg] = ofView ? 0.0 : acc2[reg];
+            }
+        }
+        pbeg += n;
+        }
     }
     // Output assembly: every wave parks its two accumulator tiles (f64 MFMA C/D layout: col = lane & 15,
     // row = (lane >> 4) + 4 * reg; zeros for a wave without an item) in its dead slab; then the
@@ -582,36 +638,7 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
     static_assert(SLAB * sizeof(T2) >= 2 * kEmitTile * 8, "tiles must fit the wave's slab");
     double* TU = reinterpret_cast<double*>(slab);
     double* TV = TU + kEmitTile;
-    double* Gbase = sel ? ((st->cur ^ 1) ? G1 : G0) : G0;
-    if (!G44 && wpi == 1 && valid) {
-        // One wave per item: the item's record goes to HBM straight from the accumulators (lane (k, c) holds rows
-        // k + 4 reg -- 4 k + reg behind the fp32 MFMA -- of column c; 16 lanes store 128 contiguous bytes): rows
-        // L..L+5 of J^T J, then J^T r and sum r^2 from the residual's row. No table, no LDS, nothing to wait for.
-        constexpr int L = C - 6, RESROW = RCOL ? 15 : 4;
-        double* G = Gbase + (int64_t)item * kGStride;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int row = MF32 ? 4 * k + reg : k + 4 * reg;
-            double val = acc[reg] + acc2[reg];
-            if (ONES) {
-                // radtan: the u-tile's / v-tile's column 3 is the true column 3 / 4 (sum Ju / sum Jv, see above)
-                const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(acc2[reg]), 0x111, 0xf, 0xf, false);
-                const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(acc2[reg]), 0x111, 0xf, 0xf, false);
-                const double fromLeft = __hiloint2double(hi, lo);       // row_shr:1: lane c <- lane c - 1
-                val = c == 3 ? acc[reg] : (c == 4 ? fromLeft : val);
-            }
-            if (row >= L && row < L + 6) {
-                G[kGRows + (row - L) * 16 + c] = (RCOL && c == 15) ? 0.0 : val;
-            } else if (row == RESROW) {
-                if (RCOL) {
-                    G[c == 15 ? kGSse : kGg + c] = val;
-                } else {
-                    G[kGg + c] = val;
-                    if (c == 4) G[kGSse] = acc[reg] + acc2[reg];
-                }
-            }
-        }
-    }
+    if (!G44 && wpi == 1 && valid) emitDirect(item);            // the (last) item's record
     __builtin_amdgcn_wave_barrier();                            // the slab is this wave's own: no workgroup barrier needed yet
     if constexpr (!G44) {
 #pragma unroll

@@ -370,6 +370,32 @@ def test_one_big_view_spans_many_gram_items(form, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("tag,name,dtype", [("g3_unittest15.npz", "radtan", "f64"), ("g2_config1_fisheye.npz", "fisheye", "f64"),
+                                            ("g3_unittest15.npz", "radtan", "f32")])
+def test_several_items_per_wave_match_one_item_per_wave(tag, name, dtype, monkeypatch):
+    """Large uniform shards let a wave of the fused kernel work through several views in a row (shared block, g_c,
+    sum r^2 carried across them, every view's own rows restarted): the per-view blocks must be bit for bit those of
+    one view per wave, the shared sums equal up to the order they are added in, and the refinement lands on the
+    reference's result."""
+    g = loadGolden(tag)
+    out = {}
+    for ipw in ("1", "3"):
+        monkeypatch.setenv("CALIB_ITEMS_PER_WAVE", ipw)
+        eng = makeEngine(name, g, dtype)
+        B, E, V, gg = eng.normalEquations(g["P0"])
+        sse, P, iters, trace = eng.refine(g["P0"], int(g["maxIters"]))
+        out[ipw] = (B, E, V, gg, sse, P, iters)
+        L = eng.L
+        eng.close()
+    a, b = out["1"], out["3"]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3][L:], b[3][L:])
+    assert np.abs(a[0] - b[0]).max() <= 1e-14 * np.abs(a[0]).max()
+    assert np.abs(a[3][:L] - b[3][:L]).max() <= 1e-13 * max(np.abs(a[3][:L]).max(), 1e-300)
+    tol = 1e-9 if dtype == "f64" else 1e-5
+    assert np.abs(b[5][:L] - g["Pfinal"][:L]).max() < tol * max(1.0, np.abs(g["Pfinal"][:L]).max())
+    assert np.abs(a[5][:L] - b[5][:L]).max() < tol * max(1.0, np.abs(g["Pfinal"][:L]).max())
+
+
 @pytest.mark.parametrize("tag,name", [("g3_unittest15.npz", "radtan"), ("g2_config1_fisheye.npz", "fisheye"),
                                       ("g5_ragged200.npz", "radtan")])
 def test_record_head_load_forms_are_bitwise_equal(tag, name, monkeypatch):
