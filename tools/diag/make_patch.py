@@ -22,25 +22,31 @@ rep('''    __shared__ __attribute__((aligned(16))) unsigned char smem[WAVES * SL
 #ifndef CALIB_IGNORE_DONE
     if (sel && st->done) return;
 #endif''')
-rep('''        for (int q0 = qbeg; q0 < qend; q0 += 64) {
-            const int q = q0 + sl;
-            const T2 m = m_n, xy = xy_n;
-            const T z = z_n;
-            if (q0 + 64 < qend) {
+rep('''        for (;; ++item) {
+        const T* vc =''','''        STAMP(0);
+        for (;; ++item) {
+        const T* vc =''')
+rep('''            if (q0 + 64 < qend) {
                 pn = pbeg + (q + 64 < qend ? q + 64 : qend - 1);
                 m_n = uv[pn]; xy_n = XY[pn]; z_n = Z[pn];
-            }''','''        STAMP(0);
-        for (int q0 = qbeg; q0 < qend; q0 += 64) {
-            const int q = q0 + sl;
-            const T2 m = m_n, xy = xy_n;
-            const T z = z_n;
-            if (q0 + 64 < qend) {
+            } else if (MULTI && item < item_last) {           // the next item's first batch (uniform items: qbeg = 0)
+                pn = pbeg + n + (sl < n ? sl : n - 1);
+                m_n = uv[pn]; xy_n = XY[pn]; z_n = Z[pn];
+            }''','''            if (q0 + 64 < qend) {
                 pn = pbeg + (q + 64 < qend ? q + 64 : qend - 1);
 #ifndef CALIB_ABLATE_GLD
                 m_n = uv[pn]; xy_n = XY[pn]; z_n = Z[pn];
 #endif
 #ifdef CALIB_STAMPS
                 __builtin_amdgcn_s_waitcnt(0x0F73);     // vmcnt(3): this batch's points have arrived
+#endif
+            } else if (MULTI && item < item_last) {           // the next item's first batch (uniform items: qbeg = 0)
+                pn = pbeg + n + (sl < n ? sl : n - 1);
+#ifndef CALIB_ABLATE_GLD
+                m_n = uv[pn]; xy_n = XY[pn]; z_n = Z[pn];
+#endif
+#ifdef CALIB_STAMPS
+                __builtin_amdgcn_s_waitcnt(0x0F73);
 #endif
             } else {
 #ifdef CALIB_STAMPS
@@ -122,16 +128,14 @@ rep('''                            contract(ja, jb, ha, hc);
                 }
             }
         }
-    }
-''','''                            contract(ja, jb, ha, hc);
+        if (!MULTI || item >= item_last) break;''','''                            contract(ja, jb, ha, hc);
                         }
                     }
                 }
                 STAMP(4);
             }
         }
-    }
-''')
+        if (!MULTI || item >= item_last) break;''')
 rep('''    if (lane == 0) { TU[kEmitZero] = 0.0; TV[kEmitZero] = 0.0; }
     __syncthreads();''','''    if (lane == 0) { TU[kEmitZero] = 0.0; TV[kEmitZero] = 0.0; }
     STAMP(5);
