@@ -508,18 +508,53 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
             T2 res;
             res.x = m.x - u;
             res.y = m.y - v;
+            // The slab stores are the dearest part of a batch: a ds_write costs its ~13 cycles on a path all four SIMDs
+            // of the CU share, with 64 or with 32 active lanes -- and a 32-row pass has only the 32 lanes that own its
+            // rows to store. So the chunks travel in PAIRS: v_permlane32_swap exchanges the upper half of chunk A with
+            // the lower half of chunk B; afterwards register A holds, for the rows of pass 0, chunk A in lanes 0-31
+            // and chunk B in lanes 32-63 (lane l + 32 carries the chunk of lane l's row), register B the same for the
+            // rows of pass 1. One full-width store per pair and pass instead of two half-empty ones: 8 instead of
+            // 13 / 14 store instructions per pass for 4 vector instructions per pair and batch.
+            constexpr int NCH = C - 5 + 1;                      // columns 5..C-1 and the residual
+            T2 ch[NCH];
+#pragma unroll
+            for (int i = 0; i < C - 5; ++i) ch[i] = Jc[5 + i];
+            ch[NCH - 1] = res;
+            auto colOf = [](int i) { return i < C - 5 ? 5 + i : (RCOL ? 15 : 4); };
+            if constexpr (HALVES == 2) {
+#pragma unroll
+                for (int i = 0; i + 1 < NCH; i += 2) {
+                    unsigned a[sizeof(T2) / 4], b[sizeof(T2) / 4];
+                    __builtin_memcpy(a, &ch[i], sizeof(T2));
+                    __builtin_memcpy(b, &ch[i + 1], sizeof(T2));
+#pragma unroll
+                    for (int d = 0; d < (int)(sizeof(T2) / 4); ++d) {
+                        const auto r = __builtin_amdgcn_permlane32_swap(a[d], b[d], false, false);
+                        a[d] = r[0];
+                        b[d] = r[1];
+                    }
+                    __builtin_memcpy(&ch[i], a, sizeof(T2));
+                    __builtin_memcpy(&ch[i + 1], b, sizeof(T2));
+                }
+            }
 #pragma unroll
             for (int half = 0; half < HALVES; ++half) {
                 if (q0 + ROWS * half >= qend) break;            // wave-uniform
                 __builtin_amdgcn_wave_barrier();
+                T2* row = slab + rowOff(sl & (ROWS - 1));
                 if (HALVES == 1 || (lane >> 5) == half) {
-                    T2* row = slab + rowOff(sl & (ROWS - 1));
                     T* rh = reinterpret_cast<T*>(row);
                     rh[0] = Jc[0].x; rh[3] = Jc[1].y; rh[4] = Jc[2].x;  // the non-zero halves of columns 0, 1, 2
+                }
+                if constexpr (HALVES == 2) {
+                    // pairs: every lane stores -- lanes 0-31 the pair's first chunk, lanes 32-63 its second, both for
+                    // row sl & 31 of this pass; columns 3, 4 are constants, set once above
 #pragma unroll
-                    for (int cc = 5; cc < C; ++cc) row[cc] = Jc[cc];    // columns 3, 4 are constants, set once above
-                    if (RCOL) row[15] = res;                    // spare 16th column carries the residual
-                    if (ONES) row[4] = res;
+                    for (int i = 0; i + 1 < NCH; i += 2) row[lane < 32 ? colOf(i) : colOf(i + 1)] = ch[i + half];
+                    if ((NCH & 1) && (lane >> 5) == half) row[colOf(NCH - 1)] = ch[NCH - 1];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i) row[colOf(i)] = ch[i];
                 }
                 __builtin_amdgcn_wave_barrier();
                 const int rows = qend - (q0 + ROWS * half);     // valid points in this pass (may exceed ROWS)

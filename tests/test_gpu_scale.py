@@ -247,8 +247,10 @@ def test_fp32_storage_path():
     eng2.setProblem(offs, s, m)
     eng2.setLmMode("two_kernel")
     B2, E2, V2, g2 = eng2.normalEquations(P0)
-    for x, y in ((B1, B2), (E1, E2), (V1, V2), (g1, g2)):
-        assert np.abs(x - y).max() <= 1e-6 * np.abs(y).max()
+    # (the gradient sums products with residuals of both signs: each fp32 mode is ~4e-5 of max |g| away from the
+    # fp64 gradient, and the two differ from each other by whatever FMA contraction the compiler chose in each kernel)
+    for x, y, tol in ((B1, B2, 1e-6), (E1, E2, 1e-6), (V1, V2, 1e-6), (g1, g2, 1e-5)):
+        assert np.abs(x - y).max() <= tol * np.abs(y).max()
     sse2, P2, iters2, _ = eng2.refine(P0, 60)
     assert relIntr(P2, P64, L) < 1e-6
     eng2.close()
