@@ -82,13 +82,34 @@ rep('''            T2 res;
             res.y = m.y - v;
             STAMP(2);
 ''')
-rep('''                if (HALVES == 1 || (lane >> 5) == half) {
-                    T2* row = slab + rowOff(sl & (ROWS - 1));''','''#ifdef CALIB_ABLATE_LDSW
-                if (false) {
-#else
+rep('''                T2* row = slab + rowOff(sl & (ROWS - 1));
                 if (HALVES == 1 || (lane >> 5) == half) {
+                    T* rh = reinterpret_cast<T*>(row);
+                    rh[0] = Jc[0].x; rh[3] = Jc[1].y; rh[4] = Jc[2].x;  // the non-zero halves of columns 0, 1, 2
+                }
+                if constexpr (HALVES == 2) {''','''                T2* row = slab + rowOff(sl & (ROWS - 1));
+#ifndef CALIB_ABLATE_LDSW
+                if (HALVES == 1 || (lane >> 5) == half) {
+                    T* rh = reinterpret_cast<T*>(row);
+                    rh[0] = Jc[0].x; rh[3] = Jc[1].y; rh[4] = Jc[2].x;  // the non-zero halves of columns 0, 1, 2
+                }
 #endif
-                    T2* row = slab + rowOff(sl & (ROWS - 1));''')
+#ifdef CALIB_ABLATE_LDSW
+                if constexpr (false) {
+#else
+                if constexpr (HALVES == 2) {
+#endif''')
+rep('''                } else {
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i) row[colOf(i)] = ch[i];
+                }''','''                } else {
+#ifndef CALIB_ABLATE_LDSW
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i) row[colOf(i)] = ch[i];
+#else
+                    asm volatile("" :: "v"(ch[0].x), "v"(ch[NCH - 1].y));
+#endif
+                }''')
 rep('''                __builtin_amdgcn_wave_barrier();
                 const int rows = qend - (q0 + ROWS * half);     // valid points in this pass (may exceed ROWS)''','''                __builtin_amdgcn_wave_barrier();
                 STAMP(3);
