@@ -494,3 +494,18 @@ def test_in_library_allreduce_world_size_1(c3):
         assert outs[1][0] < 1e-9 * n
     finally:
         dist.destroy_process_group()
+
+
+def test_kernel_variants_agree_on_random_shards():
+    """tools/fuzz_forms.py, two trials: every combination of J^T J form, views per wave and record-head load form on
+    random uniform / ragged shards -- identical per-view blocks, shared block to rounding, LM step vs the C oracle."""
+    import subprocess
+    import sys
+    from oracle import c_oracle
+    if not c_oracle.available():
+        pytest.skip("oracle/libcalib_oracle.so not built")
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_forms.py"), "2", "11"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ok: 2 trials" in r.stdout
