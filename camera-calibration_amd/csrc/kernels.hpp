@@ -82,7 +82,7 @@ inline void buildEmitTable(int C, uint32_t* tab /* kEmitTabSize */) {
 __host__ __device__ __forceinline__ constexpr int64_t jIndex(int64_t p, int c, int C) {
     return ((p >> 2) * C + c) * 4 + (p & 3);
 }
-constexpr int kSchurThreads = 128;  // 8 views (16 lanes each) per workgroup
+constexpr int kSchurThreads = 256;  // 16 views (16 lanes each) per workgroup of the update kernel (128: c4 +1 %)
 constexpr int kMaxSchurBlocks = 1024;
 
 typedef double d4 __attribute__((ext_vector_type(4)));
