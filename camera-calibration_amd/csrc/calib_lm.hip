@@ -484,7 +484,7 @@ int64_t numParams(const calib_handle_s* h) { return h->L + 6 * h->M; }
 // ============================================================================ C-ABI
 extern "C" {
 
-int calib_version(void) { return 200; }
+int calib_version(void) { return 210; }   // 2.1: calib_peer_*, block-form Gram, multi-view waves
 
 const char* calib_last_error(void) { return g_err.c_str(); }
 
