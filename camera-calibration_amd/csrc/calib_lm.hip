@@ -149,6 +149,7 @@ struct calib_handle_s {
     double peer_timeout_s = 60.0;
     bool peer_connected = false;
     bool exchange_round = false;          // the round being enqueued belongs to a sharded run
+    int* host_done = nullptr;             // pinned, device-visible: set by the update kernel when the LM loop is over
     bool lm_active = false;
     int lm_max_iters = 0;
     int rounds_enqueued = 0;
@@ -590,6 +591,7 @@ int calib_destroy(calib_handle_t h) {
             }
         }
     if (h->stage_pinned) (void)hipHostFree(h->stage_pinned);
+    if (h->host_done) (void)hipHostFree(h->host_done);
     h->uv.release(); h->XY.release(); h->Z.release(); h->VC.release(); h->J.release();
     h->r.release(); h->y.release(); h->pt_view.release(); h->view_ext.release();
     h->item_n.release(); h->view_item0.release(); h->item_view.release(); h->item_pt0.release(); h->sse_part.release();
@@ -914,6 +916,17 @@ int calib_lm_begin(calib_handle_t h, const double* P0, int max_iters, double lam
     LMState s;
     std::memset(&s, 0, sizeof(s));
     s.lam = lam_init; s.lam_min = lam_min; s.lam_max = lam_max; s.err_min = err_min;
+    if (!h->host_done) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, sizeof(int), hipHostMallocMapped) == hipSuccess) h->host_done = static_cast<int*>(p);
+        else (void)hipGetLastError();        // without the word the host falls back to synchronising checks
+    }
+    if (h->host_done) {
+        *h->host_done = 0;
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, h->host_done, 0) == hipSuccess) s.notify = static_cast<int*>(dp);
+        else (void)hipGetLastError();
+    }
     s.cur = 1;            // round 0 evaluates the "candidate" buffer 0 == P0
     s.max_iters = max_iters;
     HIP_TRY(hipMemsetAsync(h->st.p, 0, 2 * sizeof(LMState), h->stream));
@@ -1021,7 +1034,13 @@ int lm_run(calib_handle_t h, int rounds, int check_every, bool sharded) {
         }
         rc = calib_lm_update(h);
         if (rc) return rc;
-        if (check_every > 0 && (i + 1) % check_every == 0 && i + 1 < rounds) {
+        if (check_every > 0 && !sharded && h->host_done) {
+            // single shard: the device says so in host-visible memory when the loop is over -- no synchronisation, the
+            // host simply stops enqueueing (rounds already in the queue exit at once)
+            if (*static_cast<volatile int*>(h->host_done)) break;
+        } else if (check_every > 0 && (i + 1) % check_every == 0 && i + 1 < rounds) {
+            // sharded: every rank must enqueue the same rounds, so all of them look at the (replicated) flag at the
+            // same round numbers
             int done = 0;
             rc = calib_lm_done(h, &done);
             if (rc) return rc;

@@ -116,6 +116,8 @@ struct LMState {
     int error;
     int accepted_last;
     int pad;
+    int* notify;    // host-visible word the writer sets when the loop is over (null: none), so that a host that runs
+                    // ahead of the device can stop enqueueing rounds without synchronising
     double dc[kMaxL];
     double B[kMaxL * kMaxL];   // sum_views J_s^T J_s and
     double gc[kMaxL];          // sum_views J_s^T r at the CURRENT parameters (variant B re-uses them)
@@ -1373,6 +1375,8 @@ __device__ __forceinline__ bool lm_update_step(const LMState* __restrict__ in, L
             out->lam_min = in->lam_min; out->lam_max = in->lam_max; out->err_min = in->err_min;
             out->cur = cur; out->round = round + 1; out->iters = iters; out->max_iters = in->max_iters;
             out->done = done ? 1 : 0; out->error = error; out->accepted_last = accepted; out->pad = 0;
+            out->notify = in->notify;
+            if (done && in->notify) __hip_atomic_store(in->notify, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     cur_out = cur;
