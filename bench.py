@@ -86,10 +86,11 @@ def cpuBaseline(shard, cfgName, seconds=20.0):
         if c_oracle.available():
             # the C/OpenMP restatement (block-arrow / Schur form) on ALL host cores, on the whole shard
             full = (shard["viewOffsets"], shard["sensorPoints"], shard["modelPoints"])
+            c_oracle.refine(model, shard["P0"], *full, 1, lamMin=0.0, lamMax=np.inf, errMin=-np.inf)    # threads up
             t0 = time.perf_counter()
-            c_oracle.refine(model, shard["P0"], *full, 1, lamMin=0.0, lamMax=np.inf, errMin=-np.inf)
-            t1 = time.perf_counter() - t0
-            citers = int(max(2, min(200, seconds / max(t1, 1e-3))))
+            c_oracle.refine(model, shard["P0"], *full, 3, lamMin=0.0, lamMax=np.inf, errMin=-np.inf)
+            t1 = (time.perf_counter() - t0) / 3
+            citers = int(max(2, min(400, 0.75 * seconds / max(t1, 1e-3))))      # ~15 s of host work
             t0 = time.perf_counter()
             c_oracle.refine(model, shard["P0"], *full, citers, lamMin=0.0, lamMax=np.inf, errMin=-np.inf)
             tC = time.perf_counter() - t0
