@@ -77,6 +77,13 @@ class Calibrator:
         Returns (Pt_error, Arefined, Wrefined, kRefined) where Pt_error is, as in the
         reference, the error evaluated BEFORE the last update."""
         self._initializeJacobian()
+        if not isinstance(self._jac, jacobian.ProjectionJacobian):
+            # the reference's loop calls self._jac.compute(Pt, allModelPoints) every iteration (src/calibrate.py:144)
+            # and its tests put a mock there (tests/test_calibrate.py:85-90); here the Jacobian blocks are formed
+            # inside the device kernel and never pass through that seam, so an injected object cannot be honoured
+            raise TypeError(f"Calibrator._jac was replaced by {type(self._jac).__name__}: the device refinement "
+                            "evaluates the closed-form projection Jacobian inside its kernels and cannot consult an "
+                            "injected Jacobian object; use jacobian.ProjectionJacobian (or leave _jac unset)")
         maxIters = operator.index(maxIters)
         Pt = self._composeParameterVector(Ainitial, Winitial, kInitial)
         offs, sensor, model = engine.packDetections(allDetections)

@@ -120,6 +120,10 @@ struct calib_handle_s {
     int head_loads = 0;           // per-view kernels' record-head loads: 0 = by shard size, 1 = one load per value, 2 = coalesced + DPP (CALIB_HEAD_LOADS)
     int items_per_wave = 0;       // fused kernel, short uniform items: 0 = chosen per shard (CALIB_ITEMS_PER_WAVE)
     int gram_form = 0;            // fp64 fused kernel: 0 = chosen per shard, 1 = 16x16x4 tiles, 2 = 4x4x4 blocks (CALIB_GRAM_FORM)
+    int stream_mode = -1;         // fused_stream_kernel: -1 = chosen per shard, 0 = never, 1 = whenever the shard allows it (CALIB_FUSED_STREAM)
+    int stream_waves_env = 0;     // > 0: waves of the stream launch (CALIB_STREAM_WAVES); 0 = the chip's wave slots
+    int stream_share = 0;         // > 0: this problem's fused rounds run in stream form, `stream_share` 4-point groups per wave
+    int stream_waves = 0;         // waves that have work = overflow records behind the nv view records
     // LM rounds walk the points in chunks of whole views so that a chunk's compact J
     // (written by the jacobian kernel, read once by the gram kernel) can stay on-die
     struct Chunk { int64_t p0, p1; int item0, item1; };
@@ -128,6 +132,7 @@ struct calib_handle_s {
     DevBuf<unsigned char> uv, XY, Z, VC, J, r, y;   // typed by dtype
     DevBuf<int> pt_view, view_ext, item_n, view_item0, item_view;
     DevBuf<uint32_t> emit_tab;    // fused kernel's record assembly table (buildEmitTable)
+    DevBuf<int16_t> stream_ops;   // fused_stream_kernel's per-lane record offsets (buildStreamOps)
     int lm_mode = CALIB_LM_FUSED;
     int num_cus = 256;
     DevBuf<int64_t> item_pt0;
@@ -388,7 +393,35 @@ int launch_fused_t(calib_handle_s* h, const LMState* st, int sel) {
     return CALIB_OK;
 }
 
+// records of this problem's fused rounds: stream form (view records + one overflow record per wave) or one per item
+bool stream_rounds(const calib_handle_s* h) { return h->lm_mode == CALIB_LM_FUSED && h->stream_share > 0; }
+StreamMap stream_map(const calib_handle_s* h) {
+    StreamMap sm;
+    sm.share = stream_rounds(h) ? h->stream_share : 0;
+    sm.n4 = h->uniform_n / 4;
+    sm.nv = h->nv;
+    return sm;
+}
+int num_records(const calib_handle_s* h) { return std::max(h->n_items, 1) + h->stream_waves; }
+
+template <int MODEL>
+int launch_fused_stream(calib_handle_s* h, const LMState* st, int sel) {
+    const int blocks = (h->stream_waves + 3) / 4;
+    int pi = prof_begin(h, 2);
+    hipLaunchKernelGGL((fused_stream_kernel<MODEL>), dim3(blocks), dim3(256), 0, h->stream, h->P[0].p, h->P[1].p,
+                       reinterpret_cast<const double2*>(h->uv.p), reinterpret_cast<const double2*>(h->XY.p),
+                       reinterpret_cast<const double*>(h->Z.p), reinterpret_cast<const double*>(h->VC.p), h->uniform_n,
+                       h->nv, h->stream_share, h->emit_tab.p, h->stream_ops.p, st, sel, h->G[0].p, h->G[1].p, h->bpart.p);
+    prof_end(h, pi);
+    h->n_bpart = blocks;
+    LAUNCHED(h, "fused_stream_kernel");
+    return CALIB_OK;
+}
+
 int launch_fused(calib_handle_s* h, const LMState* st, int sel) {
+    if (stream_rounds(h))
+        return h->model == CALIB_MODEL_RADTAN ? launch_fused_stream<kRadtan>(h, st, sel)
+                                              : launch_fused_stream<kFisheye>(h, st, sel);
     if (h->dtype == CALIB_DTYPE_F64)
         return h->model == CALIB_MODEL_RADTAN ? launch_fused_t<kRadtan, double>(h, st, sel)
                                               : launch_fused_t<kFisheye, double>(h, st, sel);
@@ -416,15 +449,21 @@ PeerExchange next_exchange(calib_handle_s* h) {
 // shards above this many views load record heads in the coalesced, DPP-broadcast form (kernels.hpp: load_view_head)
 constexpr int kWideHeadViews = 40000;
 
+// Large shards, and shards whose views can be two records (stream form: the second record doubles the 27 per-value
+// loads of the narrow form; c3 schur +2.1 us, update +3 us -- seven coalesced rows per record cost nothing extra)
+bool wide_heads(const calib_handle_s* h) {
+    return h->head_loads == 2 || (h->head_loads == 0 && (h->nv > kWideHeadViews || stream_rounds(h)));
+}
+
 int launch_schur_reduce(calib_handle_s* h, const LMState* st, double* red) {
     const int VA = variantSize(h->L);
     if (h->nv > 0) {
         dim3 grid(h->schur_blocks, 3);
         auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, grid, dim3(kSchurBlock), 0, h->stream, h->G[0].p, h->G[1].p, st, view_items(h), h->nv,
-                               h->bpart.p, h->n_bpart, h->part.p);
+                               stream_map(h), h->bpart.p, h->n_bpart, h->part.p);
         };
-        const bool wide = h->head_loads == 2 || (h->head_loads == 0 && h->nv > kWideHeadViews);
+        const bool wide = wide_heads(h);
         if (h->L == 10) { if (wide) launch(schur_kernel<10, true>); else launch(schur_kernel<10, false>); }
         else { if (wide) launch(schur_kernel<9, true>); else launch(schur_kernel<9, false>); }
         LAUNCHED(h, "schur_kernel");
@@ -450,7 +489,7 @@ int launch_update_backsub_t(calib_handle_s* h) {
         const int blocks = std::max(1, (h->nv + kUpdViewsPerBlock - 1) / kUpdViewsPerBlock);    // one view per 16-lane group
         hipLaunchKernelGGL((update_backsub_small_kernel<L, T>), dim3(blocks), dim3(kUpdThreads), 0, h->stream,
                            h->G[0].p, h->G[1].p, st_cur(h), st_next(h), h->red, view_items(h), h->view_ext.p, h->nv,
-                           h->P[0].p, h->P[1].p, h->trace.p, reinterpret_cast<T*>(h->VC.p));
+                           stream_map(h), h->P[0].p, h->P[1].p, h->trace.p, reinterpret_cast<T*>(h->VC.p));
         LAUNCHED(h, "update_backsub_small_kernel");
         return CALIB_OK;
     }
@@ -459,9 +498,9 @@ int launch_update_backsub_t(calib_handle_s* h) {
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kSchurThreads), 0, h->stream, h->G[0].p,
                            h->G[1].p, st_cur(h), st_next(h), h->red, view_items(h), h->view_ext.p, h->nv,
-                           h->P[0].p, h->P[1].p, h->trace.p, reinterpret_cast<T*>(h->VC.p));
+                           stream_map(h), h->P[0].p, h->P[1].p, h->trace.p, reinterpret_cast<T*>(h->VC.p));
     };
-    if (h->head_loads == 2 || (h->head_loads == 0 && h->nv > kWideHeadViews)) launch(update_backsub_kernel<L, T, true>);
+    if (wide_heads(h)) launch(update_backsub_kernel<L, T, true>);
     else launch(update_backsub_kernel<L, T, false>);
     LAUNCHED(h, "update_backsub_kernel");
     return CALIB_OK;
@@ -485,7 +524,7 @@ int64_t numParams(const calib_handle_s* h) { return h->L + 6 * h->M; }
 // ============================================================================ C-ABI
 extern "C" {
 
-int calib_version(void) { return 210; }   // 2.1: calib_peer_*, block-form Gram, multi-view waves
+int calib_version(void) { return 300; }   // 3.0: stream form of the fused kernel
 
 const char* calib_last_error(void) { return g_err.c_str(); }
 
@@ -538,10 +577,25 @@ int calib_create(int model, int dtype, int device_id, calib_handle_t* out_handle
             return fail(CALIB_E_HIP, std::string("emit table: ") + hipGetErrorString(e));
         }
     }
+    {
+        int16_t ops[64 * kStreamOps];
+        const bool built = buildStreamOps(h->C, ops);
+        e = built ? h->stream_ops.alloc(64 * kStreamOps) : hipErrorUnknown;
+        if (e == hipSuccess) e = hipMemcpy(h->stream_ops.p, ops, sizeof(ops), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            h->emit_tab.release();
+            h->stream_ops.release();
+            (void)hipStreamDestroy(h->own_stream);
+            delete h;
+            return fail(CALIB_E_HIP, std::string("stream record table: ") + (built ? hipGetErrorString(e) : "inconsistent"));
+        }
+    }
     if (const char* e = std::getenv("CALIB_LM_MODE")) h->lm_mode = std::atoi(e) ? CALIB_LM_TWO_KERNEL : CALIB_LM_FUSED;
     if (const char* e = std::getenv("CALIB_HEAD_LOADS")) h->head_loads = std::strcmp(e, "narrow") == 0 ? 1 : (std::strcmp(e, "wide") == 0 ? 2 : 0);
     if (const char* e = std::getenv("CALIB_ITEMS_PER_WAVE")) h->items_per_wave = std::max(0, std::min(16, std::atoi(e)));
     if (const char* e = std::getenv("CALIB_GRAM_FORM")) h->gram_form = std::strcmp(e, "tile") == 0 ? 1 : (std::strcmp(e, "block") == 0 ? 2 : 0);
+    if (const char* e = std::getenv("CALIB_FUSED_STREAM")) h->stream_mode = std::atoi(e) > 0 ? 1 : (std::atoi(e) == 0 ? 0 : -1);
+    if (const char* e = std::getenv("CALIB_STREAM_WAVES")) h->stream_waves_env = std::max(0, std::atoi(e));
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0)
@@ -595,7 +649,7 @@ int calib_destroy(calib_handle_t h) {
     h->uv.release(); h->XY.release(); h->Z.release(); h->VC.release(); h->J.release();
     h->r.release(); h->y.release(); h->pt_view.release(); h->view_ext.release();
     h->item_n.release(); h->view_item0.release(); h->item_view.release(); h->item_pt0.release(); h->sse_part.release();
-    h->emit_tab.release();
+    h->emit_tab.release(); h->stream_ops.release();
     h->G[0].release(); h->G[1].release(); h->bpart.release(); h->part.release(); h->red_own.release();
     h->P[0].release(); h->P[1].release(); h->Peval.release(); h->trace.release();
     h->st.release(); h->st_eval.release(); h->rccl_test.release();
@@ -766,6 +820,24 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
             if (item_n[i] != un || item_pt0[i] != (int64_t)i * un || item_view[i] != (int)i) un = 0;
         h->uniform_n = un;
     }
+    {
+        // Stream form of the fused kernel (kernels.hpp: fused_stream_kernel): uniform fp64 shards whose views are whole
+        // 4-point groups and at least one batch long. One wave per wave slot of the chip (4 per SIMD), every wave the
+        // same share of groups; a share is at least two views, so a view is cut by at most one wave start. By default
+        // only where a wave gets two views or more anyway (below that, a view per wave fills the chip better).
+        h->stream_share = h->stream_waves = 0;
+        const int un = h->uniform_n;
+        const bool can = h->dtype == CALIB_DTYPE_F64 && un >= 64 && (un & 3) == 0 && MN < ((int64_t)1 << 31) && h->nv >= 1;
+        if (can && h->stream_mode != 0) {
+            const int slots = h->stream_waves_env > 0 ? h->stream_waves_env : 16 * h->num_cus;
+            const int waves = std::max(1, std::min(slots, h->nv));
+            if (h->stream_mode == 1 || h->nv >= 2 * slots) {
+                const int64_t groups = (int64_t)h->nv * (un / 4);
+                h->stream_share = (int)((groups + waves - 1) / waves);
+                h->stream_waves = (int)((groups + h->stream_share - 1) / h->stream_share);
+            }
+        }
+    }
     HIP_TRY(upload(h->item_n.p, item_n.data(), item_n.size() * 4));
     HIP_TRY(upload(h->item_view.p, item_view.data(), item_view.size() * 4));
     HIP_TRY(upload(h->item_pt0.p, item_pt0.data(), item_pt0.size() * 8));
@@ -900,8 +972,12 @@ int calib_lm_begin(calib_handle_t h, const double* P0, int max_iters, double lam
     const int64_t K = numParams(h);
     if (h->lm_mode == CALIB_LM_TWO_KERNEL)
         HIP_TRY(h->J.alloc((size_t)((h->max_chunk_points + 3) / 4 * 4) * h->C * 2 * ts));
-    HIP_TRY(h->G[0].alloc((size_t)std::max(h->n_items, 1) * kGStride));
-    HIP_TRY(h->G[1].alloc((size_t)std::max(h->n_items, 1) * kGStride));
+    for (int b = 0; b < 2; ++b) {
+        // fused_stream_kernel writes only the record entries the per-view kernels read: start from zeros
+        const bool fresh = !h->G[b].p || h->G[b].n < (size_t)num_records(h) * kGStride;
+        HIP_TRY(h->G[b].alloc((size_t)num_records(h) * kGStride));
+        if (fresh) HIP_TRY(hipMemsetAsync(h->G[b].p, 0, h->G[b].n * 8, h->stream));
+    }
     HIP_TRY(h->bpart.alloc(((size_t)std::max(h->n_items, 1) + h->chunks.size()) * kPartStride));   // <= 1 per item (+1 per chunk)
     HIP_TRY(h->part.alloc((size_t)2 * h->schur_blocks * variantSize(h->L)));
     HIP_TRY(h->red_own.alloc((size_t)reduceSize(h->L)));
@@ -1362,8 +1438,9 @@ int calib_normal_eq(calib_handle_t h, const double* P, double* out_B, double* ou
     if (out_B) std::memcpy(out_B, red.data(), (size_t)L * L * 8);
     if (out_g) std::memcpy(out_g, red.data() + 2 * L * L, (size_t)L * 8);
     if (out_E || out_V || out_g) {
-        std::vector<double> G((size_t)h->n_items * kGStride);
+        std::vector<double> G((size_t)num_records(h) * kGStride);
         std::vector<int> vi0((size_t)h->nv + 1);
+        const StreamMap sm = stream_map(h);
         HIP_TRY(hipMemcpy(G.data(), h->G[0].p, G.size() * 8, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(vi0.data(), h->view_item0.p, vi0.size() * 4, hipMemcpyDeviceToHost));
         for (int v = 0; v < h->nv; ++v) {       // nv == M here (calib_lm_begin checked)
@@ -1371,6 +1448,11 @@ int calib_normal_eq(calib_handle_t h, const double* P, double* out_B, double* ou
             std::fill(blk, blk + kGStride, 0.0);
             for (int it = vi0[v]; it < vi0[v + 1]; ++it)
                 for (int i = 0; i < kGStride; ++i) blk[i] += G[(size_t)it * kGStride + i];
+            if (sm.share > 0) {                 // stream form: the part of the view summed by a second wave
+                const int64_t first = (int64_t)v * sm.n4, w = (first + sm.n4 - 1) / sm.share;
+                if (w * sm.share > first)
+                    for (int i = 0; i < kGStride; ++i) blk[i] += G[(size_t)(sm.nv + w) * kGStride + i];
+            }
             for (int a = 0; a < 6; ++a) {
                 if (out_g) out_g[L + 6 * (int64_t)v + a] = blk[kGg + L + a];
                 for (int b = 0; b < 6; ++b)
@@ -1382,6 +1464,19 @@ int calib_normal_eq(calib_handle_t h, const double* P, double* out_B, double* ou
     }
     return CALIB_OK;
 }
+
+#ifdef CALIB_STREAM_STAMPS
+// diagnostic build only (tools/diag/): the stamped waves' rows of g_sstamps (kSStampSlots values each), then clears
+int calib_debug_stream_stamps(unsigned long long* out, int max_waves) {
+    std::vector<unsigned long long> hst((size_t)calib::kSStampWaves * calib::kSStampSlots);
+    (void)hipMemcpyFromSymbol(hst.data(), HIP_SYMBOL(calib::g_sstamps), hst.size() * 8);
+    const int nw = std::min(max_waves, calib::kSStampWaves);
+    if (out) std::memcpy(out, hst.data(), (size_t)nw * calib::kSStampSlots * 8);
+    std::fill(hst.begin(), hst.end(), 0ull);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(calib::g_sstamps), hst.data(), hst.size() * 8);
+    return 0;
+}
+#endif
 
 int calib_distort_points(int model, int64_t n, const double* x_norm, const double* k, double* out_xd) {
     if (n < 0 || (n > 0 && (!x_norm || !out_xd)) || !k) return fail(CALIB_E_INVALID, "null argument");

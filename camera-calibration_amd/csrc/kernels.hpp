@@ -728,6 +728,417 @@ __global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) 
     }
 }
 
+#ifdef CALIB_STREAM_STAMPS
+// diagnostic build only (tools/diag/build_stream_stamps.sh): per-wave s_memtime deltas of fused_stream_kernel's phases
+constexpr int kSStampWaves = 8192, kSStampSlots = 16;
+__device__ unsigned long long g_sstamps[kSStampWaves * kSStampSlots];
+#define SSTAMP(i) do { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); const unsigned long long t__ = __builtin_amdgcn_s_memtime(); tacc[i] += t__ - tlast; tlast = t__; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SSTAMP(i) do {} while (0)
+#endif
+// ---------------------------------------------------------------- fused jacobian + gram, stream form
+// The block-form fused kernel for uniform fp64 shards (every view n points, n a multiple of 4 and >= 64), with the
+// per-view fixed cost and the dead lanes of a view's last batch taken out. The shard is ONE stream of 4-point
+// groups; wave w of the launch takes groups [w share, (w + 1) share) -- the host sizes the launch to the wave
+// slots of the chip, so every SIMD gets the same number of groups whatever the view count (10 000 views of 200 points
+// on 4 096 slots used to be 2.44 rounds of one view per wave: three rounds). A wave pays ONE prologue, one first
+// wait, one workgroup partial; its batches are always 64 live points (but for the share's last), view boundaries
+// fall where they fall:
+//  * a batch inside one view evaluates its points with the view's constants in SGPRs -- requested right after the
+//    previous batch's Jacobian arithmetic is done with the registers, so they arrive while that batch is contracted;
+//    a batch that straddles a boundary uses per-lane constants: lanes 0..35 fetch the 36 doubles of the two views (one
+//    load, requested a batch ahead), stage them in 288 B of LDS, and every lane reads the 18 of its own view;
+//  * in the contraction, when the next group is the first of a new view, the finished view's record leaves STRAIGHT
+//    FROM THE ACCUMULATORS (no tile parking, no barrier): every lane knows from a table (buildStreamOps, 24 B per
+//    lane, kept in LDS) where in the 1 KiB record each of its block entries belongs -- once, or twice for an
+//    entry whose row AND column are view parameters -- and stores them there; the (b, b+2) blocks, whose u rows' and
+//    v rows' sums live in two different lanes, are completed with one ds_bpermute. Then everything that belongs
+//    to a view (rows and columns L..L+5) restarts from zero; the shared block, g_c and sum r^2 go on for the share;
+//  * records: view v's goes to slot v from the wave that holds the view's first group; what a wave sums of the
+//    view its share starts in the middle of goes to its overflow slot nv + w (StreamMap / stream_extra_item:
+//    the per-view kernels add the two). Only the entries the per-view kernels read are written: rows L..L+5 of
+//    J^T J and the view's six entries of J^T r (the record buffers are zeroed when they are allocated).
+// Everything else -- slab layout, chunk pairs, the five 4x4x4 instructions per group -- is fused_kernel's G44 form.
+constexpr int kStreamOps = 12;       // int16 byte offsets into the record per lane, -1 = nothing
+// op -> what is stored: 0, 1: d0u + d0v   2, 3: d1u + d1v   4, 5: d2 + the partner lane's d2
+//                       6: d0u  7: d0v  8: d1u  9: d1v  10: d2   (radial-tangential: the (1,1) column, see fused_kernel)
+inline bool buildStreamOps(int C, int16_t* ops /* 64 * kStreamOps */) {
+    uint32_t tab[kEmitTabSize];
+    buildEmitTable(C, tab);
+    const int L = C - 6;
+    for (int i = 0; i < 64 * kStreamOps; ++i) ops[i] = -1;
+    struct Src { int lane, acc; };          // acc: 0 d0u, 1 d0v, 2 d1u, 3 d1v, 4 d2
+    const auto laneOf = [](int k, int b, int x) { return k * 16 + b * 4 + x; };
+    // who holds entry idx = row * 16 + col of the u rows' (v rows') tile: see the block layout in fused_kernel
+    const auto locate = [&](int idx, bool vtile) -> Src {
+        const int r = idx / 16, c = idx % 16, br = r / 4, bc = c / 4;
+        if (bc == br) return {laneOf(r % 4, br, c % 4), vtile ? 1 : 0};
+        if (bc == ((br + 1) & 3)) return {laneOf(r % 4, br, c % 4), vtile ? 3 : 2};
+        if (br == ((bc + 1) & 3)) return {laneOf(c % 4, bc, r % 4), vtile ? 3 : 2};
+        const bool own = vtile ? br >= 2 : br < 2;      // (b, b+2): u rows in lanes of blocks 0, 1, v rows in 2, 3
+        return own ? Src{laneOf(r % 4, br, c % 4), 4} : Src{laneOf(c % 4, bc, r % 4), 4};
+    };
+    bool ok = true;
+    const auto put = [&](int lane, int first, int count, int slot) {
+        for (int j = first; j < first + count; ++j)
+            if (ops[lane * kStreamOps + j] < 0) { ops[lane * kStreamOps + j] = (int16_t)(slot * 8); return; }
+        ok = false;
+    };
+    for (int slot = 0; slot < kGHead; ++slot) {
+        const bool wanted = slot < kGg || (slot >= kGg + L && slot < kGg + L + 6);
+        if (!wanted) continue;
+        const int iu = (int)(tab[slot] & 0xffff), iv = (int)(tab[slot] >> 16);
+        if (iu == kEmitZero && iv == kEmitZero) continue;
+        if (iu != kEmitZero && iv != kEmitZero) {
+            const Src su = locate(iu, false), sv = locate(iv, true);
+            if (iu != iv) { ok = false; continue; }
+            if (su.lane == sv.lane) put(su.lane, su.acc == 0 ? 0 : 2, 2, slot);
+            else if (su.acc == 4 && sv.acc == 4) put(su.lane, 4, 2, slot);
+            else ok = false;
+        } else if (iu != kEmitZero) {
+            const Src su = locate(iu, false);
+            put(su.lane, su.acc == 0 ? 6 : (su.acc == 2 ? 8 : 10), 1, slot);
+        } else {
+            const Src sv = locate(iv, true);
+            put(sv.lane, sv.acc == 1 ? 7 : (sv.acc == 3 ? 9 : 10), 1, slot);
+        }
+    }
+    return ok;
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(256, 4) void fused_stream_kernel(const double* __restrict__ P0, const double* __restrict__ P1,
+                                                              const double2* __restrict__ uv, const double2* __restrict__ XY,
+                                                              const double* __restrict__ Z, const double* __restrict__ VC,
+                                                              int n, int nv, int share,
+                                                              const uint32_t* __restrict__ emit_tab,
+                                                              const int16_t* __restrict__ stream_ops,
+                                                              const LMState* __restrict__ st, int sel,
+                                                              double* __restrict__ G0, double* __restrict__ G1,
+                                                              double* __restrict__ part) {
+    using T = double;
+    using T2 = double2;
+    constexpr int C = ModelTraits<MODEL>::C, L = C - 6;
+    constexpr int ROWS = 32, WAVES = 4;
+    constexpr int SLAB = ROWS * 16 + ROWS / 2;
+    constexpr bool RCOL = C < 16, ONES = !RCOL;
+    auto rowOff = [](int r) { return r * 16 + (r >> 1); };
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WAVES * SLAB * sizeof(T2)];
+    __shared__ __attribute__((aligned(16))) double svc[WAVES][2 * kViewStride];
+    __shared__ __attribute__((aligned(16))) int16_t sops[64 * kStreamOps];
+    static_assert(SLAB * sizeof(T2) >= 2 * kEmitTile * 8, "tiles must fit the wave's slab");
+#ifdef CALIB_STREAM_STAMPS
+    unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tstart = __builtin_amdgcn_s_memtime();
+    unsigned long long tlast = tstart;
+#endif
+    if (sel && st->done) return;
+    const double* P = selectP(P0, P1, st, sel);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, k = lane >> 4;
+    const int sl = (lane & 48) | ((lane & 7) << 1) | ((lane >> 3) & 1);
+    T2* slab = reinterpret_cast<T2*>(smem) + wave * SLAB;
+    double d0u = 0.0, d0v = 0.0, d1u = 0.0, d1v = 0.0, d2u = 0.0;
+    double* Gbase = sel ? ((st->cur ^ 1) ? G1 : G0) : G0;
+    // block results: lane (i, b, j) = (k, bi, bj) holds entry (4 b + i, 4 b' + j) of block (b, b'), b' = b, b + 1, b + 2
+    const int bi = (lane >> 2) & 3, bj = lane & 3;
+    const int trow = 4 * bi + k, tcol0 = 4 * bi + bj, tcol1 = 4 * ((bi + 1) & 3) + bj, tcol2 = 4 * ((bi + 2) & 3) + bj;
+    auto ofView = [](int i) { return i >= L && i < L + 6; };
+    const bool keep0 = !(ofView(trow) || ofView(tcol0)), keep1 = !(ofView(trow) || ofView(tcol1)),
+               keep2 = !(ofView(trow) || ofView(tcol2));
+    // every wave writes the (same) whole table and every lane only ever reads back its own 24 bytes: no barrier
+    {
+        const uint2* src = reinterpret_cast<const uint2*>(stream_ops) + 3 * lane;
+        uint2* dst = reinterpret_cast<uint2*>(sops) + 3 * lane;
+        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    }
+    const int partner = bj * 16 + ((bi + 2) & 3) * 4 + k;       // holds the other rows' sums of this lane's (b, b+2) entry
+    // the finished view's record, straight from the accumulators; then what belongs to a view restarts from zero
+    auto emitView = [&](int slot) {
+        char* G = reinterpret_cast<char*>(Gbase + (int64_t)slot * kGStride);
+        const uint2* o2 = reinterpret_cast<const uint2*>(sops) + 3 * lane;
+        const uint2 oa = o2[0], ob = o2[1];
+        const double s0 = d0u + d0v, s1 = d1u + d1v;
+        const double dp = __hiloint2double(__builtin_amdgcn_ds_bpermute(partner << 2, __double2hiint(d2u)),
+                                           __builtin_amdgcn_ds_bpermute(partner << 2, __double2loint(d2u)));
+        const double s2 = d2u + dp;
+        auto put = [&](unsigned w, bool hi, double val) {
+            const int off = hi ? (int)w >> 16 : (int)(short)(w & 0xffffu);
+            if (off >= 0) *reinterpret_cast<double*>(G + off) = val;
+        };
+        put(oa.x, false, s0); put(oa.x, true, s0);
+        put(oa.y, false, s1); put(oa.y, true, s1);
+        put(ob.x, false, s2); put(ob.x, true, s2);
+        if (ONES) {
+            const uint2 oc = o2[2];
+            put(ob.y, false, d0u); put(ob.y, true, d0v);
+            put(oc.x, false, d1u); put(oc.x, true, d1v);
+            put(oc.y, false, d2u);
+        }
+        d0u = keep0 ? d0u : 0.0;  d0v = keep0 ? d0v : 0.0;
+        d1u = keep1 ? d1u : 0.0;  d1v = keep1 ? d1v : 0.0;
+        d2u = keep2 ? d2u : 0.0;
+    };
+    const int n4 = n >> 2;
+    const int w = blockIdx.x * WAVES + wave;
+    const long long gt = (long long)nv * n4, g0 = (long long)w * share;
+    const bool valid = g0 < gt;
+    if (valid) {
+        const int p0 = (int)(4 * g0);
+        const int p1 = (int)(4 * (g0 + share < gt ? g0 + share : gt));
+        int va = __builtin_amdgcn_readfirstlane(p0 / n);      // the view being accumulated
+        int vend = (va + 1) * n;                              // its end = the next boundary, in points
+        int slot = p0 != va * n ? nv + w : va;
+        Shared<MODEL, T> sp;
+        sp.load(P);
+        // the constant parts of the slab rows (see fused_kernel)
+        if (lane < ROWS) {
+            T2 c3, c4;
+            c3.x = T(1); c3.y = ONES ? T(1) : T(0);
+            c4.x = T(0); c4.y = T(1);
+            slab[rowOff(lane) + 3] = c3;
+            if (!ONES) slab[rowOff(lane) + 4] = c4;
+            T* zr = reinterpret_cast<T*>(slab + rowOff(lane));
+            zr[1] = T(0); zr[2] = T(0); zr[5] = T(0);
+        }
+        int pn = p0 + sl < p1 ? p0 + sl : p1 - 1;
+        T2 m_n = uv[pn], xy_n = XY[pn];
+        T z_n = Z[pn];
+        // does the batch at q0 hold points of two views (boundary ve strictly inside its live points)?
+        auto straddles = [&](int q0, int ve) { return ve > q0 && ve < (q0 + 64 < p1 ? q0 + 64 : p1); };
+        const int vcLast = nv * kViewStride - 1;
+        auto stagedLoad = [&](int view) {                       // lanes 0..35: the 36 doubles of views (view, view + 1)
+            const int i = view * kViewStride + (lane < 2 * kViewStride ? lane : 2 * kViewStride - 1);
+            return VC[i < vcLast ? i : vcLast];
+        };
+        double vc_n = 0.0;
+        double vcs[kViewStride];                               // one-view batches: the view's constants (SGPRs)
+#pragma unroll
+        for (int i = 0; i < kViewStride; ++i) vcs[i] = 0.0;
+        auto scalarLoad = [&](int view) {
+            const T* s = VC + (int64_t)__builtin_amdgcn_readfirstlane(view) * kViewStride;
+#pragma unroll
+            for (int i = 0; i < kViewStride - 1; ++i) vcs[i] = s[i];
+        };
+        bool strad = straddles(p0, vend);
+        if (strad) vc_n = stagedLoad(va); else scalarLoad(va);
+        const T2* src = slab + rowOff(k);                      // rows 4 s + k: + 66 chunks per group
+        const int c1 = (c + 4) & 15, c2 = (c + 8) & 15, jh = (lane >> 3) & 1;
+        const T* h0 = reinterpret_cast<const T*>(src + c) + jh;
+        const T* h2 = reinterpret_cast<const T*>(src + c2) + jh;
+        auto contract = [&](const T2& ja, const T2& jb, double ha, double hc) {
+            d0u = __builtin_amdgcn_mfma_f64_4x4x4f64(ja.x, ja.x, d0u, 0, 0, 0);
+            d0v = __builtin_amdgcn_mfma_f64_4x4x4f64(ja.y, ja.y, d0v, 0, 0, 0);
+            d1u = __builtin_amdgcn_mfma_f64_4x4x4f64(ja.x, jb.x, d1u, 0, 0, 0);
+            d1v = __builtin_amdgcn_mfma_f64_4x4x4f64(ja.y, jb.y, d1v, 0, 0, 0);
+            d2u = __builtin_amdgcn_mfma_f64_4x4x4f64(ha, hc, d2u, 0, 0, 0);
+        };
+        SSTAMP(0);
+        for (int q0 = p0; q0 < p1; q0 += 64) {
+            const int qe = q0 + 64 < p1 ? q0 + 64 : p1;
+            const int q = q0 + sl;
+            const T2 m = m_n, xy = xy_n;
+            const T z = z_n;
+            const double vcx = vc_n;
+            // a boundary inside this batch (or at its start) is passed during it: what the next batch will see
+            const bool more = q0 + 64 < p1;
+            const bool passes = vend < qe;
+            const int ve2 = passes ? vend + n : vend, va2 = passes ? va + 1 : va;
+            const bool strad2 = more && straddles(q0 + 64, ve2);
+            const int vfirst2 = ve2 <= q0 + 64 ? va2 + 1 : va2;
+            if (more) {
+                pn = q + 64 < p1 ? q + 64 : p1 - 1;
+                m_n = uv[pn]; xy_n = XY[pn]; z_n = Z[pn];
+                if (strad2) vc_n = stagedLoad(va2);
+#ifdef CALIB_STREAM_STAMPS
+                __builtin_amdgcn_s_waitcnt(0x0F74);     // vmcnt(4): this batch's points have arrived
+#endif
+            } else {
+#ifdef CALIB_STREAM_STAMPS
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+            }
+            SSTAMP(1);
+            T u, v;
+            T2 Jc[C];
+            if (!strad) {
+                jacobian_point<MODEL, T>(sp, vcs, xy.x, xy.y, z, u, v, Jc);
+            } else {
+                // two views: every lane reads the constants of its own from the staged pair
+                double* sv = svc[wave];
+                if (lane < 2 * kViewStride) sv[lane] = vcx;
+                __builtin_amdgcn_wave_barrier();
+                const int qc = q < p1 ? q : p1 - 1;               // clamped lanes follow the share's last point
+                const double2* s2 = reinterpret_cast<const double2*>(sv + (qc >= vend ? kViewStride : 0));
+                T vcl[kViewStride];
+#pragma unroll
+                for (int i = 0; i < kViewStride / 2; ++i) {
+                    const double2 t = s2[i];
+                    vcl[2 * i] = t.x;
+                    vcl[2 * i + 1] = t.y;
+                }
+                __builtin_amdgcn_wave_barrier();
+                jacobian_point<MODEL, T>(sp, vcl, xy.x, xy.y, z, u, v, Jc);
+            }
+            T2 res;
+            res.x = m.x - u;
+            res.y = m.y - v;
+#ifdef CALIB_STREAM_STAMPS
+            asm volatile("" :: "v"(res.x), "v"(res.y), "v"(Jc[C - 1].x), "v"(Jc[C - 1].y));
+            if (strad) SSTAMP(3); else SSTAMP(2);
+#endif
+            // the SGPRs of the view constants are free now: the next one-view batch's arrive during the contraction
+            if (more && !strad2) scalarLoad(vfirst2);
+            strad = strad2;
+            // chunk pairs through v_permlane32_swap: one full-width store per pair and pass (see fused_kernel)
+            constexpr int NCH = C - 5 + 1;                      // columns 5..C-1 and the residual
+            T2 ch[NCH];
+#pragma unroll
+            for (int i = 0; i < C - 5; ++i) ch[i] = Jc[5 + i];
+            ch[NCH - 1] = res;
+            auto colOf = [](int i) { return i < C - 5 ? 5 + i : (RCOL ? 15 : 4); };
+#pragma unroll
+            for (int i = 0; i + 1 < NCH; i += 2) {
+                unsigned a[4], b[4];
+                __builtin_memcpy(a, &ch[i], sizeof(T2));
+                __builtin_memcpy(b, &ch[i + 1], sizeof(T2));
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const auto r = __builtin_amdgcn_permlane32_swap(a[d], b[d], false, false);
+                    a[d] = r[0];
+                    b[d] = r[1];
+                }
+                __builtin_memcpy(&ch[i], a, sizeof(T2));
+                __builtin_memcpy(&ch[i + 1], b, sizeof(T2));
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int ps = q0 + ROWS * half;                // first point of the pass
+                if (ps >= p1) break;                            // wave-uniform
+                __builtin_amdgcn_wave_barrier();
+                T2* row = slab + rowOff(sl & (ROWS - 1));
+                if ((lane >> 5) == half) {
+                    T* rh = reinterpret_cast<T*>(row);
+                    rh[0] = Jc[0].x; rh[3] = Jc[1].y; rh[4] = Jc[2].x;  // the non-zero halves of columns 0, 1, 2
+                }
+#pragma unroll
+                for (int i = 0; i + 1 < NCH; i += 2) row[lane < 32 ? colOf(i) : colOf(i + 1)] = ch[i + half];
+                if ((NCH & 1) && (lane >> 5) == half) row[colOf(NCH - 1)] = ch[NCH - 1];
+                __builtin_amdgcn_wave_barrier();
+                SSTAMP(4);
+                const int ng = (p1 - ps >= ROWS ? ROWS : p1 - ps) >> 2;   // groups of the pass (shares are whole groups)
+                const int jb = (vend - ps) >> 2;                // the group a new view starts with (>= ng: none here)
+                if (ng == ROWS / 4 && jb >= ROWS / 4) {
+                    // a whole pass inside one view: every address is the wave's constant base plus an immediate
+                    // the operands of group s + 1 are requested before group s is contracted
+                    T2 ja = src[c], jbb = src[c1];
+                    double ha = h0[0], hc = h2[0];
+#pragma unroll
+                    for (int s = 0; s < ROWS / 4; ++s) {
+                        T2 na = ja, nb = jbb;
+                        double nha = ha, nhc = hc;
+                        if (s + 1 < ROWS / 4) {
+                            na = src[66 * (s + 1) + c]; nb = src[66 * (s + 1) + c1];
+                            nha = h0[2 * 66 * (s + 1)]; nhc = h2[2 * 66 * (s + 1)];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        contract(ja, jbb, ha, hc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        ja = na; jbb = nb; ha = nha; hc = nhc;
+                    }
+#ifdef CALIB_STREAM_STAMPS
+                    asm volatile("" :: "v"(d0u), "v"(d0v), "v"(d1u), "v"(d1v), "v"(d2u));
+#endif
+                    SSTAMP(5);
+                } else {
+                    const int sb = jb < ng ? jb : ng;
+                    // groups [from, to) of the pass on immediate offsets: entered at `from`, left at `to` (a rolled loop
+                    // with computed addresses made these passes 2.6 times as dear as the whole-view ones)
+                    auto runGroups = [&](int from, int to) {
+                        switch (from) {
+#define CALIB_GROUP_CASE(S) case S: if (to <= S) break; contract(src[66 * S + c], src[66 * S + c1], h0[2 * 66 * S], h2[2 * 66 * S]); [[fallthrough]];
+                        CALIB_GROUP_CASE(0) CALIB_GROUP_CASE(1) CALIB_GROUP_CASE(2) CALIB_GROUP_CASE(3)
+                        CALIB_GROUP_CASE(4) CALIB_GROUP_CASE(5) CALIB_GROUP_CASE(6) CALIB_GROUP_CASE(7)
+#undef CALIB_GROUP_CASE
+                        default: break;
+                        }
+                    };
+                    runGroups(0, sb);
+#ifdef CALIB_STREAM_STAMPS
+                    asm volatile("" :: "v"(d0u), "v"(d0v), "v"(d1u), "v"(d1v), "v"(d2u));
+#endif
+                    SSTAMP(6);
+                    if (jb < ng) {
+                        // the next group is the first of a new view
+                        emitView(slot);
+                        va += 1;
+                        vend += n;
+                        slot = va;
+                        SSTAMP(7);
+                        runGroups(sb, ng);
+#ifdef CALIB_STREAM_STAMPS
+                        asm volatile("" :: "v"(d0u), "v"(d0v), "v"(d1u), "v"(d1v), "v"(d2u));
+#endif
+                        SSTAMP(6);
+                    }
+                }
+            }
+        }
+        // the share's last view (whole, or cut by the share's end)
+        emitView(slot);
+    }
+    // the workgroup's partial of B, g_c, sum r^2: every wave parks its block accumulators as the two full symmetric
+    // 16 x 16 tiles in its (idle) slab; 112 threads add the four waves' entries through the index table
+    {
+        double* TU = reinterpret_cast<double*>(slab);
+        double* TV = TU + kEmitTile;
+        __builtin_amdgcn_wave_barrier();
+        TU[trow * 16 + tcol0] = d0u;  TV[trow * 16 + tcol0] = d0v;
+        TU[trow * 16 + tcol1] = d1u;  TV[trow * 16 + tcol1] = d1v;
+        TU[tcol1 * 16 + trow] = d1u;  TV[tcol1 * 16 + trow] = d1v;
+        double* T2nd = bi < 2 ? TU : TV;
+        T2nd[trow * 16 + tcol2] = d2u;
+        T2nd[tcol2 * 16 + trow] = d2u;
+        if (lane == 0) { TU[kEmitZero] = 0.0; TV[kEmitZero] = 0.0; }
+    }
+    SSTAMP(8);
+    __syncthreads();
+    SSTAMP(9);
+    if ((int)threadIdx.x < kPartStride) {
+        const uint32_t t = emit_tab[kGStride + threadIdx.x];
+        const double* T0 = reinterpret_cast<const double*>(smem);
+        double o = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < WAVES; ++wv) {
+            const double* TUw = reinterpret_cast<const double*>(reinterpret_cast<const T2*>(T0) + wv * SLAB);
+            o += TUw[t & 0xffff] + (TUw + kEmitTile)[t >> 16];
+        }
+        part[(int64_t)blockIdx.x * kPartStride + threadIdx.x] = o;
+    }
+#ifdef CALIB_STREAM_STAMPS
+    SSTAMP(10);
+    if (lane == 0 && w < kSStampWaves) {
+        unsigned long long* o = g_sstamps + (size_t)w * kSStampSlots;
+        for (int i = 0; i < 12; ++i) o[i] = tacc[i];
+        o[12] = tstart; o[13] = tlast; o[14] = 1;
+    }
+#endif
+}
+
+// ---------------------------------------------------------------- stream form: which records make up a view
+// fused_stream_kernel deals the shard's 4-point groups out to its waves in equal shares of `share` groups, whatever
+// the view boundaries. The record of view v (n4 groups) is written by the wave that holds the view's first group; a
+// wave whose share starts strictly inside a view writes what it sums of that view to its own overflow record nv + w.
+// With share >= n4 at most one wave starts inside a view, so a view is one or two records, found by arithmetic.
+struct StreamMap { int share, n4, nv; };     // share == 0: the shard's records are not in stream form
+__device__ __forceinline__ int stream_extra_item(const StreamMap& sm, int v) {
+    if (sm.share == 0) return -1;
+    const unsigned first = (unsigned)v * (unsigned)sm.n4, last = first + (unsigned)sm.n4 - 1u;
+    const unsigned w = last / (unsigned)sm.share;             // the wave that holds the view's last group
+    return w * (unsigned)sm.share > first ? sm.nv + (int)w : -1;
+}
+
 // ---------------------------------------------------------------- per-view elimination
 // 16 lanes per view, working from the head of the view's record(s): lane c < L owns row c of E, lane L the view gradient.
 __device__ __forceinline__ constexpr int tri(int m, int n) { return m * (m + 1) / 2 + n; }
@@ -757,7 +1168,7 @@ __device__ __forceinline__ double row_bcast(double v) {
 // lanes -- more work for the address coalescer, but no chain of 54 DPP moves behind the loads (c3 / c4 -0.9 us).
 // WIDE form in two steps, so that a kernel can have the next view's rows in flight while it factors this one:
 // the raw column-c elements of the six rows and of the gradient row (summed over the view's items) ...
-__device__ __forceinline__ void request_head_rows(const double* __restrict__ G, int item0, int nitems, int c,
+__device__ __forceinline__ void request_head_rows(const double* __restrict__ G, int item0, int nitems, int extra, int c,
                                                   double (&r)[7]) {
     const double* g = G + (int64_t)item0 * kGStride;
 #pragma unroll
@@ -765,6 +1176,12 @@ __device__ __forceinline__ void request_head_rows(const double* __restrict__ G, 
     r[6] = g[kGg + c];
     for (int it = 1; it < nitems; ++it) {                     // > 1 item only for views above kGramChunk points
         g += kGStride;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) r[m] += g[kGRows + m * 16 + c];
+        r[6] += g[kGg + c];
+    }
+    if (extra >= 0) {                                         // stream form: the part of the view a second wave summed
+        g = G + (int64_t)extra * kGStride;
 #pragma unroll
         for (int m = 0; m < 6; ++m) r[m] += g[kGRows + m * 16 + c];
         r[6] += g[kGg + c];
@@ -788,12 +1205,12 @@ __device__ __forceinline__ void expand_head_rows(const double (&r)[7], int c, do
 }
 
 template <int L, bool WIDE>
-__device__ __forceinline__ void load_view_head(const double* __restrict__ G, int item0, int nitems, int c,
+__device__ __forceinline__ void load_view_head(const double* __restrict__ G, int item0, int nitems, int extra, int c,
                                                double (&V)[21], double (&b)[6]) {
     const double* g = G + (int64_t)item0 * kGStride;
     if constexpr (WIDE) {
         double r[7];
-        request_head_rows(G, item0, nitems, c, r);
+        request_head_rows(G, item0, nitems, extra, c, r);
         expand_head_rows<L>(r, c, V, b);
     } else {
         const int boff = c < L ? kGRows + c : kGg + L;        // + m * 16 (view rows) resp. + m (gradient)
@@ -806,6 +1223,15 @@ __device__ __forceinline__ void load_view_head(const double* __restrict__ G, int
         }
         for (int it = 1; it < nitems; ++it) {                 // > 1 item only for views above kGramChunk points
             g += kGStride;
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+#pragma unroll
+                for (int n = 0; n <= m; ++n) V[tri(m, n)] += g[kGRows + m * 16 + L + n];
+                b[m] += g[boff + m * bstep];
+            }
+        }
+        if (extra >= 0) {                                     // stream form: the part of the view a second wave summed
+            g = G + (int64_t)extra * kGStride;
 #pragma unroll
             for (int m = 0; m < 6; ++m) {
 #pragma unroll
@@ -866,7 +1292,7 @@ __global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __r
                                                             const double* __restrict__ G1,
                                                             const LMState* __restrict__ st,
                                                             const int* __restrict__ view_item0,
-                                                            int nv, const double* __restrict__ bpart,
+                                                            int nv, StreamMap sm, const double* __restrict__ bpart,
                                                             int n_bpart, double* __restrict__ part) {
     constexpr int VA = variantSize(L);
     constexpr int kNfail = 2 * L * L + 2 * L, kSse = kNfail + 1;
@@ -912,7 +1338,7 @@ __global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __r
     if (v0 + grp < nv) {
         // view_item0 == nullptr: every view is a single item (item index == view index)
         const int v = v0 + grp, i0 = view_item0 ? view_item0[v] : v;
-        load_view_head<L, WIDE>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
+        load_view_head<L, WIDE>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, stream_extra_item(sm, v), c, V, b);
     }
     if (st->done) return;
     const bool boot = st->round == 0;
@@ -937,7 +1363,7 @@ __global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __r
         double rn[7];
         if (WIDE && more) {                                   // the next trip's seven rows: in flight during this elimination
             const int v = v0 + stride + grp, i0 = view_item0 ? view_item0[v] : v;
-            request_head_rows(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, rn);
+            request_head_rows(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, stream_extra_item(sm, v), c, rn);
         }
         if (live) {
             double invd[6];
@@ -954,7 +1380,7 @@ __global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __r
                 expand_head_rows<L>(rn, c, V, b);
             } else {                                          // the next trip's heads, behind this trip's MFMAs
                 const int v = v0 + grp, i0 = view_item0 ? view_item0[v] : v;
-                load_view_head<L, false>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
+                load_view_head<L, false>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, stream_extra_item(sm, v), c, V, b);
             }
         }
         // W^T W: K-slot k = this lane's view, six rows per view
@@ -1453,7 +1879,7 @@ template <int L, typename T, bool WIDE>
 __global__ __launch_bounds__(kSchurThreads, 4) void update_backsub_kernel(
         const double* __restrict__ G0, const double* __restrict__ G1, const LMState* __restrict__ st_in,
         LMState* __restrict__ st_out, const double* __restrict__ red, const int* __restrict__ view_item0,
-        const int* __restrict__ view_ext, int nv, double* __restrict__ P0, double* __restrict__ P1,
+        const int* __restrict__ view_ext, int nv, StreamMap sm, double* __restrict__ P0, double* __restrict__ P1,
         double* __restrict__ trace, T* __restrict__ VC) {
     const int tid = threadIdx.x, c = tid & 15;
     const bool writer = blockIdx.x == 0 && tid < 16;
@@ -1486,7 +1912,7 @@ __global__ __launch_bounds__(kSchurThreads, 4) void update_backsub_kernel(
     double rn[7];
     if (WIDE && v < nv) {
         const int i0 = view_item0 ? view_item0[v] : v;
-        request_head_rows(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, rn);
+        request_head_rows(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, stream_extra_item(sm, v), c, rn);
     }
     for (; v < nv; v += stride) {
         double V[21], b[6], invd[6], z[6];
@@ -1494,11 +1920,11 @@ __global__ __launch_bounds__(kSchurThreads, 4) void update_backsub_kernel(
             expand_head_rows<L>(rn, c, V, b);
             if (v + stride < nv) {                            // the next view's rows: in flight during this view's update
                 const int vn = v + stride, i0 = view_item0 ? view_item0[vn] : vn;
-                request_head_rows(G, i0, view_item0 ? view_item0[vn + 1] - i0 : 1, c, rn);
+                request_head_rows(G, i0, view_item0 ? view_item0[vn + 1] - i0 : 1, stream_extra_item(sm, vn), c, rn);
             }
         } else {
             const int i0 = view_item0 ? view_item0[v] : v;
-            load_view_head<L, false>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
+            load_view_head<L, false>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, stream_extra_item(sm, v), c, V, b);
         }
         eliminate(V, b, lam, invd, z);
         finish_view<L, T>(V, invd, z, coef, c, v, view_ext, Pc, Pn, VC);
@@ -1520,7 +1946,7 @@ template <int L, typename T>
 __global__ __launch_bounds__(kUpdThreads) void update_backsub_small_kernel(
         const double* __restrict__ G0, const double* __restrict__ G1, const LMState* __restrict__ st_in,
         LMState* __restrict__ st_out, const double* __restrict__ red, const int* __restrict__ view_item0,
-        const int* __restrict__ view_ext, int nv, double* __restrict__ P0, double* __restrict__ P1,
+        const int* __restrict__ view_ext, int nv, StreamMap sm, double* __restrict__ P0, double* __restrict__ P1,
         double* __restrict__ trace, T* __restrict__ VC) {
     constexpr int kSse = 2 * L * L + 2 * L + 1;
     const int tid = threadIdx.x, c = tid & 15, wave = tid >> 6;
@@ -1556,7 +1982,7 @@ __global__ __launch_bounds__(kUpdThreads) void update_backsub_small_kernel(
         }
         if (v < nv) {
             const int i0 = view_item0 ? view_item0[v] : v;
-            load_view_head<L, false>(cur ? G1 : G0, i0, view_item0 ? view_item0[v + 1] - i0 : 1, c, V, b);
+            load_view_head<L, false>(cur ? G1 : G0, i0, view_item0 ? view_item0[v + 1] - i0 : 1, stream_extra_item(sm, v), c, V, b);
             eliminate(V, b, lam, invd, z);
         }
     }

@@ -311,13 +311,19 @@ class ResidentProblem:
 
     def get(self, viewOffsets, sensorPoints, modelPoints):
         offs = np.ascontiguousarray(viewOffsets, dtype=np.int64)
-        same = (self.eng is not None and np.array_equal(offs, self._offs) and np.array_equal(modelPoints, self._model)
+        same = (self.eng is not None and self._offs is not None and np.array_equal(offs, self._offs)
+                and np.array_equal(modelPoints, self._model)
                 and (sensorPoints is None or (self._sensor is not None and np.array_equal(sensorPoints, self._sensor))))
         if not same:
             if self.eng is None:
                 self.eng = RefineEngine(self.modelId, self.dtype, self.device)
+            # the keys are PRIVATE copies (a caller that changes its arrays in place must not be compared with
+            # itself), and they describe the engine only once the upload has succeeded
+            self._offs = self._sensor = self._model = None
             self.eng.setProblem(offs, sensorPoints, modelPoints)
-            self._offs, self._sensor, self._model = offs, sensorPoints, modelPoints
+            self._offs = offs.copy()
+            self._sensor = None if sensorPoints is None else np.array(sensorPoints, dtype=np.float64, copy=True)
+            self._model = np.array(modelPoints, dtype=np.float64, copy=True)
             self.uploads += 1
         return self.eng
 

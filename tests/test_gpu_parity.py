@@ -271,6 +271,46 @@ def test_calibrator_engine_is_resident_across_calls():
     cal.close()
 
 
+def test_resident_problem_notices_in_place_changes_of_the_callers_arrays():
+    """refinePacked hands the caller's arrays straight to the resident engine: a caller that changes them IN PLACE
+    between two calls must get a new upload and a result for the new points (the keys are private copies)."""
+    g = loadGolden("g3_unittest15.npz")
+    offs, sensor, model = g["viewOffsets"], g["sensorPoints"].copy(), g["modelPoints"].copy()
+    cal = cca.Calibrator(cca.RadialTangentialModel())
+    a = cal.refinePacked(g["P0"], offs, sensor, model, 3)
+    assert cal._resident.uploads == 1
+    b = cal.refinePacked(g["P0"], offs, sensor, model, 3)
+    assert cal._resident.uploads == 1 and a[0] == b[0] and np.array_equal(a[1], b[1])
+    sensor += 0.25                                    # same object, other values
+    c = cal.refinePacked(g["P0"], offs, sensor, model, 3)
+    assert cal._resident.uploads == 2 and c[0] != a[0]
+    fresh = cca.Calibrator(cca.RadialTangentialModel())
+    d = fresh.refinePacked(g["P0"], offs, sensor.copy(), model, 3)
+    assert c[0] == d[0] and np.array_equal(c[1], d[1])
+    model[:, 2] += 1e-3
+    cal.refinePacked(g["P0"], offs, sensor, model, 3)
+    assert cal._resident.uploads == 3
+    cal.close()
+    fresh.close()
+
+
+def test_injected_jacobian_is_refused_not_ignored():
+    """The reference's loop calls self._jac.compute every iteration (src/calibrate.py:144) and its tests inject a
+    mock there (tests/test_calibrate.py:85-90). The device loop cannot consult such an object: it says so."""
+    from unittest.mock import MagicMock
+    g = loadGolden("g3_unittest15.npz")
+    offs = g["viewOffsets"]
+    dets = [(g["sensorPoints"][a:b], g["modelPoints"][a:b]) for a, b in zip(offs[:-1], offs[1:])]
+    cal = cca.Calibrator(cca.RadialTangentialModel())
+    cal._jac = MagicMock()
+    with pytest.raises(TypeError, match="injected Jacobian"):
+        cal.refineCalibrationParameters(g["A0"], list(g["W0"]), tuple(g["k0"]), dets, 2)
+    cal._jac = None
+    sse, A, W, k = cal.refineCalibrationParameters(g["A0"], list(g["W0"]), tuple(g["k0"]), dets, 2)
+    assert isinstance(sse, float) and isinstance(cal._jac, cca.ProjectionJacobian)
+    cal.close()
+
+
 def test_calibrator_dropin_surface():
     # the reference's own hot-path tests, against the drop-in (tests/test_calibrate.py:80-133)
     g = loadGolden("g3_unittest15.npz")

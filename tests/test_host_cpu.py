@@ -141,3 +141,17 @@ def test_mathutils_helpers_vs_reference_known_answers():
     with pytest.raises(ValueError):
         mu.projectStandard(np.zeros((4, 2)))
     assert mu.radians(180.0) == np.pi and np.array_equal(mu.normalize(np.array([2.0, 4.0])), [0.5, 1.0])
+
+
+def test_injected_jacobian_is_refused_before_anything_runs():
+    """src/calibrate.py:144 consults self._jac every iteration; the drop-in's device loop cannot, and refuses an
+    object that is not its own ProjectionJacobian instead of silently ignoring it (no device needed to say so)."""
+    from unittest.mock import MagicMock
+    g = loadGolden("g3_unittest15.npz")
+    offs = g["viewOffsets"]
+    dets = [(g["sensorPoints"][a:b], g["modelPoints"][a:b]) for a, b in zip(offs[:-1], offs[1:])]
+    cal = cca.Calibrator(cca.RadialTangentialModel())
+    cal._jac = MagicMock()
+    with pytest.raises(TypeError, match="injected Jacobian"):
+        cal.refineCalibrationParameters(g["A0"], list(g["W0"]), tuple(g["k0"]), dets, 2)
+    cal._jac.compute.assert_not_called()

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 w=${1:-c3}; shift
 for v in "" noV noVM noVMW noVMWG; do
-  if [ -n "$v" ]; then export CALIB_LM_LIBRARY=$R/camera-calibration_amd/lib/diag_$v/libcalib_lm.so; else unset CALIB_LM_LIBRARY; fi
+  if [ -n "$v" ]; then export CALIB_LM_LIBRARY=$R/tools/diag/lib/$v/libcalib_lm.so; else unset CALIB_LM_LIBRARY; fi
   t=$(python3 $R/tools/kexp.py --workload $w --steps 100 "$@" | grep -o "fused [0-9.]* us")
   case "$v" in
     "") what="the whole kernel";;

@@ -1,5 +1,5 @@
 """Where a wave of the fused kernel spends its life: per-phase s_memtime deltas from the diagnostic build
-(tools/diag/build_diag.sh -> lib/diag_stamps), averaged over the waves of one launch.
+(tools/diag/build_diag.sh -> tools/diag/lib/stamps), averaged over the waves of one launch.
 usage: python tools/diag/fused_stamps.py [workload] [views]"""
 import ctypes
 import os
@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
-os.environ["CALIB_LM_LIBRARY"] = os.path.join(ROOT, "camera-calibration_amd", "lib", "diag_stamps", "libcalib_lm.so")
+os.environ["CALIB_LM_LIBRARY"] = os.path.join(ROOT, "tools", "diag", "lib", "stamps", "libcalib_lm.so")
 import numpy as np                                   # noqa: E402
 import camera_calibration_amd as cca                 # noqa: E402
 from camera_calibration_amd import synthetic, _native  # noqa: E402

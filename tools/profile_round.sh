@@ -30,7 +30,7 @@ for u in ubench6 ubench7 ubench8 mfma4x4_layout; do
 done
 echo "ubench done"
 # per-phase stamps and in-situ ablation of the fused kernel (diagnostic builds: bash tools/diag/build_diag.sh first)
-if [ -f camera-calibration_amd/lib/diag_stamps/libcalib_lm.so ]; then
+if [ -f tools/diag/lib/stamps/libcalib_lm.so ]; then
   { for a in "c3" "c5 125000" "c2" "c4 12500"; do python3 tools/diag/fused_stamps.py $a; done
     for a in "c3" "c5 --views 125000" "c2" "c4 --views 12500"; do bash tools/diag/fused_ablation.sh $a; done; } 2>&1 | grep -vE "amdgpu.ids" > gpurun_out/prof/fused_diag.txt
   echo "fused diag done"
