@@ -11,7 +11,10 @@ kernel; `--lm-mode two_kernel` materialises the compact J in HBM between a jacob
 kernel instead), per-view Schur elimination, (N > 1: one RCCL all-reduce of the reduce
 buffer), accept/reject + L x L solve, back-substitution. Termination tests are disabled for the timed region
 (lam_min = 0, lam_max = inf, err_min = -inf) so that exactly K iterations execute, each
-with full work. Weak scaling: every rank holds `views` views of the config.
+with full work. `value` is WEAK scaling (every rank holds `views` views of the config); at N > 1 the line also
+carries a `strong` block -- the config's GLOBAL problem (c3: 10 000 views, c5: 1 000 000) split N ways -- and, in
+`exchange`, the same K steps timed with every carrier of the per-round sum that passes its self-test (the library's
+own ncclAllReduce, torch.distributed.all_reduce, the in-kernel peer exchange); `value` is taken with RCCL.
 One JSON line is printed by rank 0.
 """
 import argparse
@@ -118,6 +121,19 @@ def cpuBaseline(shard, cfgName, seconds=20.0):
     }
 
 
+def strongShardRange(totalViews, world, rank):
+    """views [start, end) of `rank` when `totalViews` views of one global problem are split over `world` ranks"""
+    from camera_calibration_amd import distributed
+    return distributed.strongShardRange(totalViews, world, rank)
+
+
+class Carrier:
+    """one way of carrying the per-round sum over the ranks: its own engine (the peer exchange and the in-library
+    communicator are properties of a handle), the ShardedLM on top"""
+    def __init__(self, name, eng, lm, describe):
+        self.name, self.eng, self.lm, self.describe = name, eng, lm, describe
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,13 +145,16 @@ def main():
     ap.add_argument("--views", type=int, default=None, help="views per GPU (default: the config's)")
     ap.add_argument("--noise", type=float, default=0.1, help="sensor noise sigma in px")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["both", "weak", "strong"], default="both",
+                    help="N > 1: 'weak' = every rank holds the config's per-GPU views (this is `value`); 'strong' = the "
+                         "config's global problem split N ways (block `strong`); 'both' (default) measures the two")
     ap.add_argument("--allreduce", choices=["auto", "peer", "direct", "torch"], default="auto",
-                    help="the one exchange per LM step at N > 1. 'peer': the reduce kernel itself sums over the ranks, "
-                         "point-to-point over xGMI through IPC-mapped slot memory (no collective launch); 'direct': "
-                         "ncclAllReduce issued by the library on its own stream; 'torch': torch.distributed.all_reduce on "
-                         "the bound buffer. 'auto' (default) takes the first of these whose start-up self-test (a checked "
-                         "exchange against a deadline) passes on EVERY rank. peer and direct have been exercised with "
-                         "several processes on one GPU only")
+                    help="the one exchange per LM step at N > 1. 'direct': ncclAllReduce issued by the library on its own "
+                         "stream; 'torch': torch.distributed.all_reduce on the bound buffer; 'peer': the reduce kernel itself "
+                         "sums over the ranks, point-to-point over xGMI through IPC-mapped slot memory (no collective "
+                         "launch). 'auto' (default) times every one of them whose start-up self-test passes on EVERY rank "
+                         "(block `exchange`) and takes `value` with RCCL: direct if it came up, else torch. The peer exchange "
+                         "has been exercised with several processes on one GPU only: opt-in for `value`")
     ap.add_argument("--lm-mode", default="fused", choices=["fused", "two_kernel"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
@@ -152,6 +171,8 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # the host driver supports dmabuf IPC only: RCCL and the peer exchange need this in every rank's environment
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch
     import camera_calibration_amd as cca
@@ -172,153 +193,231 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group("gloo")
+    devTorch = torch.device("cuda", local)
 
     cfg = dict(synthetic.CONFIGS[args.workload])
-    viewsPerGpu = args.views or cfg["views"]
-    if args.workload == "c5" and args.views is None:
-        viewsPerGpu = cfg["views"] // 8      # the config is stated for 8 GPUs
-    if args.workload == "c4" and args.views is None:
-        viewsPerGpu = cfg["views"] // 8
-    t0 = time.perf_counter()
-    shard = synthetic.makeShard(cfg, viewStart=rank * viewsPerGpu, numViews=viewsPerGpu,
-                                noiseSigma=args.noise, device=local)
-    tGen = time.perf_counter() - t0
-    MNlocal = int(shard["viewOffsets"][-1])
-
-    eng = cca.RefineEngine(cfg["model"], cfg["dtype"], local)
-    t0 = time.perf_counter()
-    eng.setProblem(shard["viewOffsets"], shard["sensorPoints"], shard["modelPoints"])
-    tUpload = time.perf_counter() - t0
-    eng.setLmMode(args.lm_mode)
+    # the configs c4 and c5 are stated for 8 GPUs: their per-GPU shard is an eighth
+    perGpuDefault = cfg["views"] // 8 if args.workload in ("c4", "c5") else cfg["views"]
+    viewsPerGpu = args.views or perGpuDefault
     lmOpts = dict(lamInit=1e-3, lamMin=0.0, lamMax=float("inf"), errMin=-float("inf"))
+    SEG = 100
+    if args.steps > SEG:
+        sys.exit(f"bench.py: --steps is at most {SEG} (lambda leaves the fp64 range in longer runs with the stop rule off)")
+    # HIP events around the dominant kernel's launches inside the timed region, on the stream they are launched on.
+    # An event pair keeps a launch from being dispatched back to back with its neighbours (c3: +12 us per LM round when
+    # every launch is bracketed), so every 16th launch is timed -- whatever --steps is.
+    PROF_EVERY = 16 if args.lm_mode == "fused" else 1
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()      # the engine's own stream was synchronised by the segment's lmEnd
 
-    # A timed SEGMENT is exactly K = --steps LM iterations of one refinement: lmBegin (upload of P0, state reset)
-    # and the bootstrap pass that evaluates P0 are issued and drained BEFORE the clock starts, lmEnd (download of
-    # P and the trace) runs after it stops -- they are per-refinement costs, reported as segment_overhead_ms.
-    # With the stop rule disabled lambda overflows after ~310 consecutive rejections at the noise floor, so a
-    # segment holds at most SEG iterations and every segment restarts from the same perturbed P0 (lambda 1e-3,
-    # src/calibrate.py:142). The segment is repeated R times (R agreed by all ranks from one calibration
-    # segment, so that the timed phase lasts >= 0.5 s) and the MEDIAN segment is reported: a 100-iteration c3
-    # segment is 8 ms, too short for the clocks and for a sampling profiler to see.
-    SEG = 100
-    if args.steps > SEG:
-        sys.exit(f"bench.py: --steps is at most {SEG} (lambda leaves the fp64 range in longer runs with the stop rule off)")
-    allReduceKind = None
+    def makeEngine(shard):
+        eng = cca.RefineEngine(cfg["model"], cfg["dtype"], local)
+        t0 = time.perf_counter()
+        eng.setProblem(shard["viewOffsets"], shard["sensorPoints"], shard["modelPoints"])
+        tUp = time.perf_counter() - t0
+        eng.setLmMode(args.lm_mode)
+        return eng, tUp
+
+    def makeCarriers(shard, eng0, want):
+        """-> list of Carrier, the one `value` is taken with first. Every carrier is self-tested and agreed on by all
+        ranks before it is used; the first engine is reused by the first carrier that comes up."""
+        out = []
+        spare = [eng0]
+
+        def engine():
+            return spare.pop() if spare else makeEngine(shard)[0]
+
+        if want in ("auto", "direct") and args.backend == "nccl":
+            e = engine()
+            ar = distributed.directAllReduce(e)
+            if ar is not None:
+                out.append(Carrier("rccl_direct", e, distributed.ShardedLM(e, ar), "ncclAllReduce issued by the library on its own stream"))
+            else:
+                spare.append(e)
+                if want == "direct":
+                    sys.exit("bench.py --allreduce direct: the in-library all-reduce could not be set up")
+        if want in ("auto", "torch"):
+            e = engine()
+            out.append(Carrier("torch", e, distributed.ShardedLM(e, distributed.torchAllReduce(e, devTorch)),
+                               "torch.distributed.all_reduce"))
+        if want in ("auto", "peer") and world > 1:
+            e = engine()
+            ar = distributed.peerExchange(e)
+            if ar is not None:
+                out.append(Carrier("peer", e, distributed.ShardedLM(e, ar),
+                                   "summed inside the reduce kernel, point-to-point over xGMI (IPC-mapped slot memory)"))
+            else:
+                spare.append(e)
+                if want == "peer":
+                    sys.exit("bench.py --allreduce peer: the peer exchange could not be set up")
+        if not out:                                            # e.g. --allreduce peer with one rank: torch's all-reduce
+            e = engine()
+            out.append(Carrier("torch", e, distributed.ShardedLM(e, distributed.torchAllReduce(e, devTorch)),
+                               "torch.distributed.all_reduce"))
+        for e in spare:
+            e.close()
+        return out
+
+    def measure(shard, eng, lm, minSeconds, profile):
+        """R timed segments of exactly --steps LM iterations on `eng` (through `lm` when sharded).
+        A timed SEGMENT is exactly K = --steps LM iterations of one refinement: lmBegin (upload of P0, state reset)
+        and the bootstrap pass that evaluates P0 are issued and drained BEFORE the clock starts, lmEnd (download of
+        P and the trace) runs after it stops -- they are per-refinement costs, reported as segment_overhead_ms.
+        With the stop rule disabled lambda overflows after ~310 consecutive rejections at the noise floor, so a
+        segment holds at most SEG iterations and every segment restarts from the same perturbed P0 (lambda 1e-3,
+        src/calibrate.py:142). The segment is repeated R times (R agreed by all ranks from one calibration
+        segment, so that the timed phase lasts >= --min-seconds) and the MEDIAN segment is reported."""
+        state = {"P": shard["P0"], "iters": 0, "trace": [], "sse": float("nan")}
+
+        def drain():
+            eng.lmDone()                  # synchronises the engine's stream (reads the done flag)
+            torch.cuda.synchronize()
+
+        def segment(k, timed=True):
+            tb = time.perf_counter()
+            if lm is not None:
+                lm.begin(shard["P0"], SEG, **lmOpts)          # lmBegin + bootstrap round
+            else:
+                eng.lmBegin(shard["P0"], SEG, **lmOpts)
+                eng.lmRun(1)
+            drain()
+            if timed:
+                barrier()
+            t0 = time.perf_counter()
+            if lm is not None:
+                lm.run(k)
+            else:
+                eng.lmRun(k)
+            drain()
+            if timed:
+                barrier()
+            t1 = time.perf_counter()
+            sse_, P_, it_, tr_ = eng.lmEnd()
+            t2 = time.perf_counter()
+            state["P"], state["sse"] = P_, sse_
+            state["iters"] += it_
+            state["trace"].append(tr_)
+            return t1 - t0, (t0 - tb) + (t2 - t1)
+
+        # Everything slow is done before the warm-up, so that the device is not left idle between the warm-up
+        # and the timed region: after >= 20 ms of idleness the GPU's clocks have dropped and the next ~1 ms of
+        # work runs slow. So: event pool and collector first, then an untimed spin-up that brings the clocks up
+        # (setup, like generating the data), the W warm-up steps, then the timed segments back to back.
+        import gc
+        if profile:
+            eng.profileEnable(True, every=PROF_EVERY)         # creates the event pool (tens of ms, once)
+        gc.collect()
+        gc.disable()              # no collector pauses inside the timed region (ranks wait for the slowest each round)
+        tSpin = time.perf_counter()
+        for _ in range(3):
+            segment(SEG, timed=False)                          # clock spin-up, ~25 ms of device work
+        tSpin = time.perf_counter() - tSpin
+        if args.warmup > 0:
+            segment(min(args.warmup, SEG), timed=False)
+        tCal, _ = segment(args.steps)                          # one calibration segment fixes the repeat count on every rank
+        if dist is not None:
+            tc = torch.tensor([tCal], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+            tCal = float(tc.item())
+        R = int(min(301, max(5, np.ceil(minSeconds / max(tCal, 1e-6)))))
+        R += 1 - R % 2                                         # odd: the median is one of the segments
+        itersBefore = state["iters"]
+        state["trace"] = []
+        if profile:
+            eng.profileEnable(True, every=PROF_EVERY)         # counters back to zero (cheap: the pool exists)
+        segTimes, segOver = np.zeros(R), np.zeros(R)
+        tPhase = time.perf_counter()
+        for j in range(R):
+            segTimes[j], segOver[j] = segment(args.steps)
+        tPhase = time.perf_counter() - tPhase
+        gc.enable()
+        if dist is not None:                                   # per segment: the slowest rank
+            tt = torch.from_numpy(np.concatenate((segTimes, segOver))).to("cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            both = tt.cpu().numpy()
+            segTimes, segOver = both[:R], both[R:]
+        res = {"elapsed": float(np.median(segTimes)), "R": R, "segTimes": segTimes, "segOver": segOver, "tPhase": tPhase,
+               "tSpin": tSpin, "iters": state["iters"] - itersBefore, "total": args.steps * R, "sse": state["sse"], "P": state["P"],
+               "trace": np.vstack(state["trace"]) if state["trace"] else np.zeros((0, 5 + eng.L))}
+        if profile:
+            res["prof"] = [eng.profileRead(i) for i in range(3)]
+            eng.profileEnable(False)
+        return res
+
+    def globalPoints(MNlocal):
+        if dist is None:
+            return MNlocal
+        n = torch.tensor([MNlocal], dtype=torch.int64, device="cuda")
+        dist.all_reduce(n)
+        return int(n.item())
+
+    # ------------------------------------------------------------------ main block (= `value`): weak unless --scaling strong
+    viewStart = rank * viewsPerGpu
+    strongOnly = dist is not None and args.scaling == "strong"
+    if strongOnly:
+        totalViews = cfg["views"] if args.views is None else args.views * world
+        viewStart, v1 = strongShardRange(totalViews, world, rank)
+        viewsPerGpu = v1 - viewStart
+    t0 = time.perf_counter()
+    shard = synthetic.makeShard(cfg, viewStart=viewStart, numViews=viewsPerGpu, noiseSigma=args.noise, device=local)
+    tGen = time.perf_counter() - t0
+    MNlocal = int(shard["viewOffsets"][-1])
+    eng, tUpload = makeEngine(shard)
     ranksSeen = 1
+    carriers = []
     if dist is not None:
-        allReduce = None
-        if args.allreduce in ("auto", "peer") and world > 1:
-            allReduce = distributed.peerExchange(eng)
-            if allReduce is None and args.allreduce == "peer":
-                sys.exit("bench.py --allreduce peer: the peer exchange could not be set up")
-            if allReduce is not None:
-                allReduceKind = "summed inside the reduce kernel, point-to-point over xGMI (IPC-mapped slot memory)"
-        if allReduce is None and args.allreduce in ("auto", "direct") and args.backend == "nccl":
-            allReduce = distributed.directAllReduce(eng)
-            if allReduce is None and args.allreduce == "direct":
-                sys.exit("bench.py --allreduce direct: the in-library all-reduce could not be set up")
-            if allReduce is not None:
-                allReduceKind = "ncclAllReduce issued by the library on its own stream"
-        if allReduce is None:
-            allReduce = distributed.torchAllReduce(eng, torch.device("cuda", local))
-            allReduceKind = "torch.distributed.all_reduce"
-        lm = distributed.ShardedLM(eng, allReduce)
+        carriers = makeCarriers(shard, eng, args.allreduce)
         # how many ranks the process group really has (not WORLD_SIZE): every rank contributes a one
-        seen = torch.ones(1, dtype=torch.int32, device=torch.device("cuda", local) if args.backend == "nccl" else "cpu")
+        seen = torch.ones(1, dtype=torch.int32, device=devTorch if args.backend == "nccl" else "cpu")
         dist.all_reduce(seen)
         ranksSeen = int(seen.item())
-    state = {"P": shard["P0"], "iters": 0, "trace": [], "sse": float("nan")}
+        eng = carriers[0].eng
+    main = carriers[0] if carriers else None
+    exchange = {}
+    m = measure(shard, eng, main.lm if main else None, args.min_seconds, profile=True)
+    if main:
+        exchange[main.name] = m["elapsed"] / args.steps * 1e3
+    for c in carriers[1:]:                                     # the same K steps with the other carriers
+        mc = measure(shard, c.eng, c.lm, min(args.min_seconds, 0.25), profile=False)
+        exchange[c.name] = mc["elapsed"] / args.steps * 1e3
+    MNglobal = globalPoints(MNlocal)
 
-    def drain():
-        eng.lmDone()                  # synchronises the engine's stream (reads the done flag)
-        torch.cuda.synchronize()
-
-    def segment(k, timed=True):
-        """one refinement of k iterations -> (seconds for the k iterations, seconds of begin + bootstrap + end)"""
-        tb = time.perf_counter()
-        # every segment is begun with the same iteration capacity (the trace buffer is sized by it)
-        if dist is not None:
-            lm.begin(shard["P0"], SEG, **lmOpts)          # lmBegin + bootstrap round
+    # ------------------------------------------------------------------ strong block: the config's global problem / N
+    strong = None
+    if dist is not None and args.scaling == "both":
+        totalViews = cfg["views"] if args.views is None else args.views * world
+        v0, v1 = strongShardRange(totalViews, world, rank)
+        if v1 - v0 == viewsPerGpu and world * viewsPerGpu == totalViews:
+            # the weak shard IS the strong shard (c4 / c5 at N = 8): measured once
+            strong = {"note": "identical to the weak block at this N", "value": MNglobal * args.steps / m["elapsed"],
+                      "ms_per_step": m["elapsed"] / args.steps * 1e3, "global_views": totalViews, "views_per_gpu": v1 - v0}
         else:
-            eng.lmBegin(shard["P0"], SEG, **lmOpts)
-            eng.lmRun(1)
-        drain()
-        if timed:
-            barrier()
-        t0 = time.perf_counter()
-        if dist is not None:
-            lm.run(k)
-        else:
-            eng.lmRun(k)
-        drain()
-        if timed:
-            barrier()
-        t1 = time.perf_counter()
-        sse_, P_, it_, tr_ = eng.lmEnd()
-        t2 = time.perf_counter()
-        state["P"], state["sse"] = P_, sse_
-        state["iters"] += it_
-        state["trace"].append(tr_)
-        return t1 - t0, (t0 - tb) + (t2 - t1)
+            sshard = synthetic.makeShard(cfg, viewStart=v0, numViews=v1 - v0, noiseSigma=args.noise, device=local)
+            seng, _ = makeEngine(sshard)
+            scar = makeCarriers(sshard, seng, {"rccl_direct": "direct", "torch": "torch", "peer": "peer"}[main.name])
+            ms = measure(sshard, scar[0].eng, scar[0].lm, min(args.min_seconds, 0.3), profile=False)
+            sglobal = globalPoints(int(sshard["viewOffsets"][-1]))
+            strong = {"value": sglobal * args.steps / ms["elapsed"], "unit": "point-residuals/s",
+                      "lm_iters_per_s": args.steps / ms["elapsed"], "ms_per_step": ms["elapsed"] / args.steps * 1e3,
+                      "global_views": totalViews, "views_per_gpu": v1 - v0, "global_points": sglobal,
+                      "allreduce": scar[0].name, "segments": int(ms["R"]), "valid": bool(ms["iters"] == ms["total"]),
+                      "what": f"the config's global problem ({totalViews} views) split over {world} ranks, views [{v0}, {v1}) "
+                              "on rank 0; speed-up = this value / the N = 1 line's value"}
+            for c in scar:
+                c.eng.close()
+        strong["scaling"] = "strong"
 
-    # Everything slow is done before the warm-up, so that the device is not left idle between the warm-up
-    # and the timed region: after >= 20 ms of idleness the GPU's clocks have dropped and the next ~1 ms of
-    # work runs slow. So: event pool and collector first, then an untimed spin-up that brings the clocks up
-    # (setup, like generating the data), the W warm-up steps, then the timed segments back to back.
-    import gc
-    # HIP events around the dominant kernel's launches inside the timed region, on the stream they are
-    # launched on. An event pair keeps a launch from being dispatched back to back with its neighbours
-    # (c3: +12 us per LM round when every launch is bracketed), so every PROF_EVERY-th launch is timed.
-    PROF_EVERY = max(1, min(16, args.steps // 6)) if args.lm_mode == "fused" else 1
-    eng.profileEnable(True, every=PROF_EVERY)             # creates the event pool (tens of ms, once)
-    gc.collect()
-    gc.disable()              # no collector pauses inside the timed region (ranks wait for the slowest each round)
-    tSpin = time.perf_counter()
-    for _ in range(3):
-        segment(SEG, timed=False)                          # clock spin-up, ~25 ms of device work
-    tSpin = time.perf_counter() - tSpin
-    if args.warmup > 0:
-        segment(min(args.warmup, SEG), timed=False)
-    # one calibration segment fixes the repeat count on every rank
-    tCal, _ = segment(args.steps)
-    if dist is not None:
-        tc = torch.tensor([tCal], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
-        tCal = float(tc.item())
-    R = int(min(301, max(5, np.ceil(args.min_seconds / max(tCal, 1e-6)))))
-    R += 1 - R % 2                                         # odd: the median is one of the segments
-    itersBefore = state["iters"]
-    state["trace"] = []
-    eng.profileEnable(True, every=PROF_EVERY)             # counters back to zero (cheap: the pool exists)
-    segTimes, segOver = np.zeros(R), np.zeros(R)
-    tPhase = time.perf_counter()
-    for j in range(R):
-        segTimes[j], segOver[j] = segment(args.steps)
-    tPhase = time.perf_counter() - tPhase
-    gc.enable()
-    if dist is not None:                                   # per segment: the slowest rank
-        tt = torch.from_numpy(segTimes.copy()).to("cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        segTimes = tt.cpu().numpy()
-    elapsed = float(np.median(segTimes))
-    jacMs, jacN = eng.profileRead(0)
-    gramMs, gramN = eng.profileRead(1)
-    fusedMs, fusedN = eng.profileRead(2)
-    eng.profileEnable(False)
     # the same upload once more: what a caller pays per calib_set_problem once the handle's pinned staging exists
     # (the first call above also pays for pinning 8 MiB and the first use of the packing kernel)
     t0 = time.perf_counter()
     eng.setProblem(shard["viewOffsets"], shard["sensorPoints"], shard["modelPoints"])
     tUpload2 = time.perf_counter() - t0
-    sse, P = state["sse"], state["P"]
-    iters = state["iters"] - itersBefore
-    trace = np.vstack(state["trace"]) if state["trace"] else np.zeros((0, 5 + eng.L))
-    total = args.steps * R
+    elapsed, R, segTimes, segOver = m["elapsed"], m["R"], m["segTimes"], m["segOver"]
+    sse, P, iters, total, trace = m["sse"], m["P"], m["iters"], m["total"], m["trace"]
+    (jacMs, jacN), (gramMs, gramN), (fusedMs, fusedN) = m.get("prof", [(0.0, 0)] * 3)
     twoKernelMsPerStep = None
     jacSteps = gramSteps = args.steps
     if rank == 0 and args.lm_mode == "fused":
@@ -345,13 +444,6 @@ def main():
         except Exception as e:
             print(f"bench: two-kernel pass skipped: {e}", file=sys.stderr)
 
-    if dist is not None:
-        n = torch.tensor([MNlocal], dtype=torch.int64, device="cuda")
-        dist.all_reduce(n)
-        MNglobal = int(n.item())
-    else:
-        MNglobal = MNlocal
-
     if rank == 0:
         L = eng.L
         w = 8 if cfg["dtype"] == "f64" else 4
@@ -376,39 +468,36 @@ def main():
                    "avg_launch_ms": jacAvgMs, "launches_timed": jacN}
         if fusedN:
             fusedAvgMs = fusedMs / fusedN
-            fusedPts = MNlocal
-            # ALGORITHMIC matrix flops: J^T J as executed on full 16x16 tiles, 2 x 2048 flop per 4 points.
-            # fp64 items of more than two batches are contracted from 4x4 blocks instead (v_mfma_f64_4x4x4_4b, the
-            # symmetric half only: 5 x 512 flop per 4 points) -- `mfma_flops_executed_per_launch` says which.
-            mfmaFlops = 4 * 16 * 16 * fusedPts
-            blockForm = cfg["dtype"] == "f64" and shard["pointsPerView"] > 128
-            mfmaExecuted = (5 * 512 // 4 if blockForm else 4 * 16 * 16) * fusedPts
-            # Matrix and vector fp64 work draw on one budget: the data sheet gives both 78.6 TFLOP/s, and what the
-            # chip sustains with every CU busy is lower and depends on the instruction (tools/ubench/ubench6-8,
-            # profiles/r02_ubench.txt: v_mfma_f64_16x16x4 46, v_mfma_f64_4x4x4_4b 76, v_fma_f64 62 TFLOP/s).
-            # `achieved` counts the VALU flops of every lane of every 64-lane batch the kernel executes;
-            # `useful_frac` counts a view's last, partly filled batch only for its live lanes.
-            batches = viewsPerGpu * (-(-shard["pointsPerView"] // 64))
+            sec = fusedAvgMs * 1e-3
+            fusedPts = MNlocal                                 # live points: one launch = every point of the shard once
             f64 = cfg["dtype"] == "f64"
-            valuFlops = valuPerBatch * batches if (valuPerBatch and f64) else 0.0
-            valuUseful = valuPerBatch * fusedPts / 64.0 if (valuPerBatch and f64) else 0.0
-            tf = (mfmaFlops + valuFlops) / (fusedAvgMs * 1e-3) / 1e12
-            # fp32 storage (configs[3]): the Gram runs on v_mfma_f32_16x16x4_f32, priced against the fp32 matrix peak;
-            # its fp32 VALU flops are not in profiles/pmc_fused.json, so `achieved` counts the matrix flops only
             peak = FP64_MATRIX_PEAK_TFLOPS if f64 else FP32_MATRIX_PEAK_TFLOPS
+            # `frac` is SURVEY 8(d)'s contract: the matrix flops of J^T J and J^T r, 4 C^2 + 4 C per LIVE point (C = 16 / 15),
+            # over the launch's duration, against the dense matrix peak of the dtype. Three more labelled figures beside
+            # it, none of them built from flops of dead lanes: what the matrix instructions actually execute (the block
+            # form builds the symmetric half: 5 x 512 flop per 4 points; the tile forms 2 x 2048), the contract flops plus
+            # the fp64 VALU flops of the per-point model (a PMC measurement, per live point), and the HBM side.
+            contractFlops = (4 * C * C + 4 * C) * fusedPts
+            stream = eng.fusedForm()[0] > 0
+            blockForm = f64 and (stream or shard["pointsPerView"] > 128)
+            mfmaExecuted = (5 * 512 // 4 if blockForm else 4 * 16 * 16) * fusedPts
+            valuUseful = valuPerBatch * fusedPts / 64.0 if (valuPerBatch and f64) else None
+            tfl = lambda fl: fl / sec / 1e12
             mfmaName = "v_mfma_f32_16x16x4_f32" if not f64 else ("v_mfma_f64_4x4x4_4b_f64" if blockForm else "v_mfma_f64_16x16x4_f64")
-            mainRoof = {"kernel": "fused_kernel (jacobian blocks + " + mfmaName + " J^T J, J on-chip)",
-                        "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
-                        "frac": tf / peak,
-                        "useful_frac": (mfmaFlops + valuUseful) / (fusedAvgMs * 1e-3) / 1e12 / peak,
+            kname = "fused_stream_kernel" if stream else "fused_kernel"
+            mainRoof = {"kernel": kname + " (jacobian blocks + " + mfmaName + " J^T J, J on-chip)",
+                        "bound": "mfma", "achieved": tfl(contractFlops), "peak": peak, "unit": "TFLOP/s",
+                        "frac": tfl(contractFlops) / peak,
+                        "frac_is": "SURVEY 8(d): (4 C^2 + 4 C) matrix flops per live point / launch duration / dense matrix peak",
+                        "frac_executed": tfl(mfmaExecuted) / peak,
+                        "frac_mfma_plus_valu_useful": (tfl(contractFlops + valuUseful) / peak) if valuUseful else None,
+                        "hbm_frac": 5 * w * fusedPts / sec / 1e9 / HBM_PEAK_GBS,
                         "traffic": fusedTraffic, "traffic_source": pmcSource if fusedTraffic else None,
-                        "mfma_flops_per_launch": mfmaFlops, "mfma_flops_executed_per_launch": mfmaExecuted,
-                        "valu_fp64_flops_per_launch": valuFlops,
+                        "mfma_flops_per_launch": contractFlops, "mfma_flops_executed_per_launch": mfmaExecuted,
+                        "valu_fp64_flops_per_launch_live_points": valuUseful,
+                        "valu_flops_source": pmcSource if valuPerBatch else "none: profiles/pmc_fused.json has no entry",
                         "sustained_whole_chip_TFLOPs_measured": {"v_mfma_f64_16x16x4": 46.4, "v_mfma_f64_4x4x4_4b": 75.8,
                                                                  "v_fma_f64": 61.8, "source": "profiles/r02_ubench.txt"},
-                        "valu_flops_source": pmcSource if valuPerBatch else "none: profiles/pmc_fused.json has no entry",
-                        "mfma_only_frac": mfmaFlops / (fusedAvgMs * 1e-3) / 1e12 / peak,
-                        "frac_executed": (mfmaExecuted + valuFlops) / (fusedAvgMs * 1e-3) / 1e12 / peak,
                         "points_per_launch": fusedPts,
                         "algorithmic_hbm_bytes_per_launch": 5 * w * fusedPts,
                         "avg_launch_ms": fusedAvgMs, "launches_timed": fusedN,
@@ -425,21 +514,31 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "timing": {"what": "median over `segments` timed segments of exactly `steps` LM iterations each (max over "
-                               "ranks per segment); lmBegin, the bootstrap pass and lmEnd are outside the segments",
+                               "ranks per segment); lmBegin, the bootstrap pass and lmEnd are outside the segments "
+                               "(round 1 timed ONE region, a mean that included them: `ms_per_step_whole_refinement` is "
+                               "that definition)",
                        "segments": int(R), "segment_ms_min": float(segTimes.min() * 1e3),
                        "segment_ms_median": float(np.median(segTimes) * 1e3), "segment_ms_max": float(segTimes.max() * 1e3),
                        "segment_overhead_ms": float(np.median(segOver) * 1e3),
-                       "timed_phase_s": float(tPhase)},
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                       "ms_per_step_whole_refinement": float(np.mean(segTimes + segOver) / args.steps * 1e3),
+                       "ms_per_refinement": float(np.mean(segTimes + segOver) * 1e3),
+                       "timed_phase_s": float(m["tPhase"])},
+            "higher_is_better": True, "scaling": "strong" if strongOnly else "weak", "vs_baseline": None,
             "dtype": cfg["dtype"], "data": "synthetic",
             "config": {"workload": f"{args.workload}: {viewsPerGpu} views x {shard['pointsPerView']} pts per GPU, "
                                    f"{cfg['model']}, {cfg['dtype']}, sensor noise {args.noise} px",
                        "views_per_gpu": viewsPerGpu, "points_per_view": shard["pointsPerView"],
-                       "global_points": MNglobal, "distortion": cfg["model"], "parallelism": f"views-sharded x{world}", "allreduce": allReduceKind,
+                       "global_points": MNglobal, "distortion": cfg["model"], "parallelism": f"views-sharded x{world}",
+                       "allreduce": main.describe if main else None,
+                       "allreduce_used_for_value": main.name if main else None,
                        "ranks_seen": ranksSeen,
-                       "exchange_selftest": None if dist is None else ("torch.distributed.all_reduce needs none" if allReduceKind.startswith("torch")
+                       "exchange_selftest": None if main is None else ("torch.distributed.all_reduce needs none" if main.name == "torch"
                                                                         else "exact sums of rank-dependent values over all ranks, against a deadline, passed on every rank"),
                        "lm_mode": args.lm_mode},
+            "exchange": None if dist is None else {"ms_per_step": exchange, "what": "the same K steps of the weak block with every "
+                                                   "carrier of the per-round sum that passed its self-test on every rank",
+                                                   "backend": args.backend},
+            "strong": strong,
             "roofline": mainRoof,
             "roofline_jacobian_kernel": jacRoof,
             "two_kernel_ms_per_step": twoKernelMsPerStep,
@@ -460,7 +559,7 @@ def main():
                                                                    / np.maximum(np.abs(shard["Ptrue"][:L]), 1.0)))},
             "setup_s": {"generate": tGen, "pack_upload": tUpload, "pack_upload_second_call": tUpload2,
                         "pack_upload_second_call_GBps": (MNlocal * 40 / tUpload2 / 1e9) if tUpload2 > 0 else None,
-                        "clock_spinup_300_untimed_iterations": tSpin},
+                        "clock_spinup_300_untimed_iterations": m["tSpin"]},
         }
         if iters != total:
             # with the stop rule disabled lambda still overflows to inf after ~310 consecutive rejections
@@ -473,7 +572,10 @@ def main():
             except Exception as e:
                 out["cpu_baseline"] = {"error": str(e)}
         print(json.dumps(out))
-    eng.close()
+    for c in carriers:
+        c.eng.close()
+    if not carriers:
+        eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

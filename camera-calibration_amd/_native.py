@@ -33,6 +33,7 @@ SIGNATURES = {
     "calib_set_stream": (ctypes.c_int, [_h, ctypes.c_void_p, ctypes.c_int]),
     "calib_set_problem": (ctypes.c_int, [_h, ctypes.c_int64, _c_int64_p, _c_double_p, _c_double_p]),
     "calib_set_lm_mode": (ctypes.c_int, [_h, ctypes.c_int]),
+    "calib_fused_form": (ctypes.c_int, [_h, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "calib_num_shared": (ctypes.c_int, [_h, _c_int_p]),
     "calib_num_params": (ctypes.c_int, [_h, _c_int64_p]),
     "calib_eval": (ctypes.c_int, [_h, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_double_p]),
@@ -97,6 +98,11 @@ def loadLibrary():
     global _lib
     if _lib is not None:
         return _lib
+    # Multi-process GPU work (RCCL, the peer exchange's hipIpc* mappings) needs the dmabuf form of HIP IPC on
+    # hosts whose driver supports no other: without it hipIpcGetMemHandle fails with "invalid argument". The
+    # variable is read when the HIP runtime initialises, so it is set here, before the runtime is loaded (a
+    # value the caller exported wins).
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if "torch" not in sys.modules:
         # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so). When this library is
         # loaded first it binds /opt/rocm's copy and a later `import torch` finds no devices

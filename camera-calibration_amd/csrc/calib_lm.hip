@@ -154,7 +154,8 @@ struct calib_handle_s {
     double peer_timeout_s = 60.0;
     bool peer_connected = false;
     bool exchange_round = false;          // the round being enqueued belongs to a sharded run
-    int* host_done = nullptr;             // pinned, device-visible: set by the update kernel when the LM loop is over
+    int* host_done = nullptr;             // pinned, device-visible: 1 = the update kernel says the LM loop is over, 2 = a peer exchange gave up
+    int* host_done_dev = nullptr;         // the same word as the device sees it
     bool lm_active = false;
     int lm_max_iters = 0;
     int rounds_enqueued = 0;
@@ -439,6 +440,7 @@ PeerExchange next_exchange(calib_handle_s* h) {
     x.slots = h->peer_slots.p;
     for (int r = 0; r < kPeerInline; ++r) x.slot8[r] = r < (int)h->peer_slot_host.size() ? h->peer_slot_host[(size_t)r] : nullptr;
     x.fault = h->peer_flags.p;
+    x.notify = h->host_done_dev;
     x.timeout_ticks = (unsigned long long)(h->peer_timeout_s * 1e8);      // wall_clock64 counts at 100 MHz
     x.epoch = ++h->peer_epoch;
     x.world = h->peer_world;
@@ -670,6 +672,13 @@ int calib_set_lm_mode(calib_handle_t h, int mode) {
     if (mode != CALIB_LM_FUSED && mode != CALIB_LM_TWO_KERNEL) return fail(CALIB_E_INVALID, "unknown LM mode");
     if (h->lm_active) return fail(CALIB_E_STATE, "cannot change the LM mode inside a run");
     h->lm_mode = mode;
+    return CALIB_OK;
+}
+
+int calib_fused_form(calib_handle_t h, int* out_share, int* out_waves) {
+    if (!h || !out_share || !out_waves) return fail(CALIB_E_INVALID, "null argument");
+    *out_share = stream_rounds(h) ? h->stream_share : 0;
+    *out_waves = stream_rounds(h) ? h->stream_waves : 0;
     return CALIB_OK;
 }
 
@@ -996,12 +1005,16 @@ int calib_lm_begin(calib_handle_t h, const double* P0, int max_iters, double lam
         void* p = nullptr;
         if (hipHostMalloc(&p, sizeof(int), hipHostMallocMapped) == hipSuccess) h->host_done = static_cast<int*>(p);
         else (void)hipGetLastError();        // without the word the host falls back to synchronising checks
+        void* dp = nullptr;
+        if (h->host_done && hipHostGetDevicePointer(&dp, h->host_done, 0) == hipSuccess) h->host_done_dev = static_cast<int*>(dp);
+        else (void)hipGetLastError();
     }
     if (h->host_done) {
+        // a run that was begun and never ended (an exception between lmBegin and lmEnd) may still have update kernels
+        // in flight that would set the word AFTER this reset: drain them first
+        if (h->lm_active) SYNC_H(h);
         *h->host_done = 0;
-        void* dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, h->host_done, 0) == hipSuccess) s.notify = static_cast<int*>(dp);
-        else (void)hipGetLastError();
+        s.notify = h->host_done_dev;
     }
     s.cur = 1;            // round 0 evaluates the "candidate" buffer 0 == P0
     s.max_iters = max_iters;
@@ -1110,6 +1123,9 @@ int lm_run(calib_handle_t h, int rounds, int check_every, bool sharded) {
         }
         rc = calib_lm_update(h);
         if (rc) return rc;
+        if (peers && h->host_done && *static_cast<volatile int*>(h->host_done) == 2)
+            return fail(CALIB_E_HIP, "peer exchange: a rank's contribution did not arrive before the deadline "
+                                     "(the ranks no longer run in lockstep, or a peer died); no further rounds are enqueued");
         if (check_every > 0 && !sharded && h->host_done) {
             // single shard: the device says so in host-visible memory when the loop is over -- no synchronisation, the
             // host simply stops enqueueing (rounds already in the queue exit at once)

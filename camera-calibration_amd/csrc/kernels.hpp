@@ -1436,7 +1436,8 @@ constexpr int kPeerInline = 8;         // ranks whose slot pointers travel in th
 struct PeerExchange {
     unsigned long long* const* slots;  // [world] rank d's slot memory as mapped on this device (device array)
     unsigned long long* slot8[kPeerInline];  // the first 8 of them by value: no dependent load before the stores
-    int* fault;
+    int* fault;                        // device word: a spin of this handle has timed out
+    int* notify;                       // host-visible word (or null): 2 = stop enqueueing rounds, the exchange is broken
     unsigned long long timeout_ticks;
     unsigned epoch;                    // > 0, +1 per exchange; identical on every rank
     int world, rank;
@@ -1457,6 +1458,10 @@ __device__ __forceinline__ u32x4 cell_load(const unsigned long long* cell) {
 
 __device__ __forceinline__ double peer_sum(const PeerExchange& x, int i, double t, int lane) {
     const unsigned par = x.epoch & 1u;
+    // Once a spin of this handle has given up (a peer died, the ranks left lockstep) the exchange is not retried: every
+    // later kernel returns NaN at once instead of spinning to its own deadline (64 self-test rounds, or the rounds a
+    // host has enqueued ahead, would otherwise wait one full timeout EACH).
+    if (__hip_atomic_load(x.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return __builtin_nan("");
     double v = 0.0;
     if (lane < x.world) {
         unsigned long long* base = nullptr, * own = nullptr;
@@ -1486,6 +1491,7 @@ __device__ __forceinline__ double peer_sum(const PeerExchange& x, int i, double 
             }
             if ((unsigned long long)(wall_clock64() - t0) > x.timeout_ticks) {
                 __hip_atomic_store(x.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (x.notify) __hip_atomic_store(x.notify, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 v = __builtin_nan("");
                 break;
             }
@@ -1522,9 +1528,12 @@ __global__ __launch_bounds__(64) void reduce_kernel(const double* __restrict__ p
     double t = v[0];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-    // the finished flag is looked at only now: its load travels with the partials' instead of ahead of them
-    if (st->done) return;
+    // the finished flag is looked at only now: its load travels with the partials' instead of ahead of them.
+    // A round that comes after the end of the loop still takes part in the exchange (with whatever it summed): the
+    // epochs advance per ENQUEUED round on every rank, and two parities are only enough while every epoch is used
+    const bool done = st->done != 0;
     if (x.world > 1) t = peer_sum(x, i, __shfl(t, 0, 64), lane);
+    if (done) return;
     if (lane == 0) red[i] = t;
 }
 

@@ -6,9 +6,10 @@ contiguous range of views resident in its HBM and eliminates their 6x6 blocks lo
 What is shared is the L x L Schur system: per LM round every rank contributes its partial
 sums (reduce buffer of calib_lm.h: 444 doubles for L = 10, 364 for L = 9) to ONE sum over the ranks, after
 which every rank takes the identical accept/reject decision and solves the identical L x L system
-redundantly. No other data-path exchange. The sum has three carriers, tried in this order: the engine's
-reduce kernel exchanging its elements point-to-point over xGMI (peerExchange), the library's own
-ncclAllReduce (directAllReduce), torch.distributed.all_reduce on the bound buffer (torchAllReduce).
+redundantly. No other data-path exchange. The sum has three carriers: the library's own ncclAllReduce
+(directAllReduce, the default), torch.distributed.all_reduce on the bound buffer (torchAllReduce, the
+fallback), and -- opt-in, CALIB_ALLREDUCE=peer -- the engine's reduce kernel exchanging its elements
+point-to-point through IPC-mapped slot memory (peerExchange; exercised between processes on one GPU only).
 
 The driver is generic over the shard engine (RefineEngine on the GPU; tests drive the
 same code with a CPU test double over gloo).
@@ -37,6 +38,15 @@ def partitionViews(viewOffsets, worldSize):
         bounds.append(min(max(v, lo), hi))
     bounds.append(M)
     return [(bounds[r], bounds[r + 1]) for r in range(worldSize)]
+
+
+def strongShardRange(totalViews, worldSize, rank):
+    """Strong scaling of ONE uniform global problem: views [start, end) of `rank` when `totalViews` views are dealt
+    out to `worldSize` ranks in contiguous ranges whose sizes differ by at most one."""
+    totalViews, worldSize, rank = int(totalViews), int(worldSize), int(rank)
+    if worldSize < 1 or not 0 <= rank < worldSize or totalViews < 0:
+        raise ValueError("strongShardRange: need 0 <= rank < worldSize and totalViews >= 0")
+    return totalViews * rank // worldSize, totalViews * (rank + 1) // worldSize
 
 
 def validateGlobalProblem(viewOffsets):
@@ -274,13 +284,15 @@ def refineDistributed(modelName, P0, viewOffsets, sensorPoints, modelPoints, max
         err = e
     _raiseTogether(dist, torch, err, okDevice)
     if onGpu:
-        # CALIB_ALLREDUCE = peer | direct | torch | auto (default): the exchange inside the reduce kernel over
-        # xGMI, the library's own ncclAllReduce, torch.distributed.all_reduce; auto tries them in that order.
-        # Each is self-tested and agreed on by all ranks before it is used.
+        # CALIB_ALLREDUCE = auto (default) | direct | torch | peer. auto = RCCL: the library's own ncclAllReduce
+        # (whole rounds from C), else torch.distributed.all_reduce. peer = the exchange inside the reduce kernel,
+        # point-to-point through IPC-mapped slot memory: OPT-IN, because it has only ever run between processes
+        # that share one GPU (no xGMI link crossed). Each carrier is self-tested and agreed
+        # on by all ranks before it is used; a carrier that does not come up falls through to the next.
         want = os.environ.get("CALIB_ALLREDUCE", "auto")
-        if want in ("peer", "auto") and world > 1:
+        if want == "peer" and world > 1:
             allReduce = peerExchange(eng)
-        if allReduce is None and want in ("direct", "auto") and dist.get_backend() == "nccl":
+        if allReduce is None and want in ("direct", "auto", "peer") and dist.get_backend() == "nccl":
             allReduce = directAllReduce(eng)
         if allReduce is None:
             allReduce = torchAllReduce(eng, torch.device("cuda", eng.device))

@@ -119,6 +119,13 @@ class RefineEngine:
         ids = {"fused": nat.LM_FUSED, "two_kernel": nat.LM_TWO_KERNEL}
         nat.check(self._lib.calib_set_lm_mode(self._h, ids[mode] if isinstance(mode, str) else int(mode)))
 
+    def fusedForm(self):
+        """-> (share, waves): share > 0 when the loaded problem's fused rounds run in the stream form (4-point groups
+        per wave, waves of the launch), (0, 0) for one view item per wave (calib_fused_form)"""
+        share, waves = ctypes.c_int(0), ctypes.c_int(0)
+        nat.check(self._lib.calib_fused_form(self._h, ctypes.byref(share), ctypes.byref(waves)))
+        return share.value, waves.value
+
     def _P(self, P):
         P = np.ascontiguousarray(np.asarray(P, dtype=np.float64).ravel())
         if P.shape[0] != self.K:

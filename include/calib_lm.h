@@ -81,6 +81,13 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
  * Both produce the same blocks (fixed, identical summation order per view item). */
 enum { CALIB_LM_FUSED = 0, CALIB_LM_TWO_KERNEL = 1 };
 int calib_set_lm_mode(calib_handle_t h, int mode);
+/* Which form of the fused kernel the loaded problem's rounds run in (decided by calib_set_problem from the shard's
+ * shape; CALIB_FUSED_STREAM=0|1 and CALIB_STREAM_WAVES override it for tests and tuning).
+ *   *out_share  > 0: stream form -- uniform fp64 shards (every view n points, n % 4 == 0, n >= 64, at least two views
+ *               per wave slot of the chip): the shard's 4-point groups are dealt out to `*out_waves` waves in equal
+ *               shares of `*out_share` groups, batches run across view boundaries, and a view cut by a wave start has
+ *               a second (overflow) record; 0: one view item per wave (or several whole items per wave). */
+int calib_fused_form(calib_handle_t h, int* out_share, int* out_waves);
 
 int calib_num_shared(calib_handle_t h, int* out_L);          /* L                          */
 int calib_num_params(calib_handle_t h, int64_t* out_K);       /* K = L + 6*num_views        */

@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libcalib_oracle.so")
+# CALIB_ORACLE_LIBRARY: another build of the same source (oracle/_asan/: the sanitizer build of `make -C oracle asan`)
+_LIB = os.environ.get("CALIB_ORACLE_LIBRARY") or os.path.join(_HERE, "libcalib_oracle.so")
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int64)
 _lib = None

@@ -42,6 +42,22 @@ def test_partition_views_balanced_and_contiguous():
     assert sum(b - a for a, b in parts) == 2 and all(b >= a for a, b in parts)
 
 
+def test_strong_scaling_partition_arithmetic():
+    """bench.py's `strong` block deals the config's GLOBAL views (c3: 10 000, c5: 1 000 000) out to the ranks: every
+    view exactly once, contiguous, sizes within one of each other; N = 8 of c5 is the config's own per-GPU shard."""
+    for total in (10000, 1000000, 100000, 7, 1):
+        for world in (1, 2, 3, 4, 8):
+            parts = [distributed.strongShardRange(total, world, r) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == total
+            assert all(a1 == b0 for (a0, a1), (b0, b1) in zip(parts[:-1], parts[1:]))
+            sizes = [b - a for a, b in parts]
+            assert sum(sizes) == total and max(sizes) - min(sizes) <= 1
+    assert distributed.strongShardRange(1000000, 8, 3) == (375000, 500000)
+    assert distributed.strongShardRange(10000, 4, 0) == (0, 2500)
+    with pytest.raises(ValueError):
+        distributed.strongShardRange(10, 2, 2)
+
+
 def test_validate_global_problem():
     distributed.validateGlobalProblem(np.array([0, 3, 9]))
     with pytest.raises(np.linalg.LinAlgError):

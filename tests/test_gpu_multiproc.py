@@ -123,10 +123,15 @@ def _peerWorker(rank, world, port, case, outDir):
             # rank 1 does not take part in a further exchange: the others stop waiting after the deadline and say so
             dist.barrier()
             if rank != 1:
+                # 40 rounds are enqueued at once with a 0.5 s deadline each: only the first may spin it out, the rest
+                # see the fault word and return at once (they used to wait 40 x 0.5 s)
+                import time
+                t0 = time.perf_counter()
                 try:
-                    eng.peerSelfTest(1, 0.5)
+                    eng.peerSelfTest(40, 0.5)
                 except RuntimeError as e:
                     out["error"] = str(e)
+                out["lost_seconds"] = time.perf_counter() - t0
             dist.barrier()
         eng.peerShutdown()
         eng.close()
@@ -143,3 +148,4 @@ def test_peer_exchange_selftest_and_bounded_spin(tmp_path, world, case):
     assert all(int(o["ok"]) == 1 for o in outs)
     if case == "lost_rank":
         assert "did not arrive" in str(outs[0]["error"]) and str(outs[1]["error"]) == ""
+        assert float(outs[0]["lost_seconds"]) < 5.0, float(outs[0]["lost_seconds"])

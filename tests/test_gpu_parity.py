@@ -530,6 +530,61 @@ def test_dataset_generator_reproduces_reference_datasets():
         assert np.abs(yfull[ok] - refy[ok]).max() < 1e-9
 
 
+def test_noisy_dataset_and_calibration_match_the_reference():
+    """tests/itest_main.py:31-52, the reference's NOISY case (sigma = 0.1 px; golden g9 = that run of the reference):
+    the dataset generator draws the same noise -- per view the reference re-seeds the global generator, draws the pose
+    (choice, 4 x uniform) and then the noise (src/dataset.py:64-70, src/virtualcamera.py:47-48, src/noise.py:16) --
+    so the detections, crop decisions included, come out the same; calibrateCamera then lands inside the reference's
+    own tolerances (A within 2.0, k within 0.05) and on the reference's own estimate, trace and all."""
+    from camera_calibration_amd import dataset
+    g = loadGolden("g9_noisy.npz")
+    w, h = (int(v) for v in g["imageSize"])
+    ds = dataset.createSyntheticDatasetRadTan(g["Atrue"], w, h, tuple(g["ktrue"]), dataset.NoiseModel(float(g["noiseSigma"])))
+    dets = ds.getCornerDetectionsInSensorCoordinates()
+    offs = np.concatenate(([0], np.cumsum([s.shape[0] for s, m in dets])))
+    assert np.array_equal(offs, g["viewOffsets"])                       # same crop decisions on the noisy points
+    assert np.abs(np.vstack([s for s, m in dets]) - g["sensorPoints"]).max() < 1e-9
+    assert np.array_equal(np.vstack([m for s, m in dets]), g["modelPoints"])
+    sse, A, W, k = cca.calibrateCamera(dets, "radtan", 100)
+    assert np.allclose(A, g["Atrue"], atol=2.0) and np.allclose(k, g["ktrue"], atol=0.05)      # itest_main.py:51-52
+    # ... and the reference's own result for these detections (39 iterations to the noise floor, sse 126.77)
+    assert abs(sse - float(g["sseFinal"])) <= 1e-6 * float(g["sseFinal"])
+    assert np.abs(A - g["Afinal"]).max() < 1e-4 and np.abs(np.array(k) - g["kfinal"]).max() < 1e-6
+    # the LM path from the reference's start point: same decisions while they are well separated
+    cal = cca.Calibrator(cca.RadialTangentialModel())
+    cal.refineCalibrationParameters(g["A0"], list(g["W0"]), tuple(g["k0"]), dets, 100)
+    tr, ref = cal.lastTrace, g["traceIterErrLam"]
+    n = min(12, tr.shape[0], ref.shape[0])
+    assert np.array_equal(tr[:n, 3], ref[:n, 2])                         # lambda sequence = accept / reject decisions
+    shown = np.minimum(tr[:n, 1], np.where(tr[:n, 4] == 1, tr[:n, 2], np.inf))
+    assert np.allclose(shown, ref[:n, 1], rtol=1e-6)                     # printed error (src/calibrate.py:158-159)
+    # both runs end when lambda leaves (1e-10, 1e10) at the noise floor (sse 126.77...), where a step changes the error
+    # in its 12th digit and accept / reject is decided by the order of the additions: the count may differ (33 vs 39)
+    assert abs(tr[-1, 1] - ref[-1, 1]) <= 1e-9 * ref[-1, 1] and tr.shape[0] < 100
+    cal.close()
+
+
+def test_fisheye_end_to_end_through_the_facade():
+    """tests/itest_main.py:54-79: calibrateCamera(allDetections, "fisheye", 10) -- DLT, extrinsics, the linear
+    distortion estimate and the refinement, all through the facade. The reference only asserts that nothing raises
+    (its TODO: convergence); golden g2-fisheye holds what the reference computes for config 1, start point and result."""
+    g = loadGolden("g2_config1_fisheye.npz")
+    offs = g["viewOffsets"]
+    dets = [(g["sensorPoints"][a:b], g["modelPoints"][a:b]) for a, b in zip(offs[:-1], offs[1:])]
+    cal = cca.Calibrator(cca.FisheyeModel())
+    A0, W0, k0 = cal.estimateCalibrationParameters(dets)
+    assert np.abs(A0 - g["A0"]).max() < 1e-5 and np.abs(np.array(k0) - g["k0"]).max() < 1e-6
+    assert np.abs(np.array(W0) - g["W0"]).max() < 1e-6
+    sse, A, W, k = cca.calibrateCamera(dets, "fisheye", 10)
+    assert isinstance(sse, float) and A.shape == (3, 3) and len(W) == len(dets) and len(k) == 4
+    ref = g["traceIterErrLam"]                                           # the reference converges in 8 iterations here
+    assert ref.shape[0] <= 10
+    assert np.abs(A - g["Afinal"]).max() < 1e-6 and np.abs(np.array(k) - g["kfinal"]).max() < 1e-8
+    assert np.abs(np.array(W) - g["Wfinal"]).max() < 1e-6
+    assert np.allclose(A, g["Atrue"], atol=1e-6) and np.allclose(k, g["ktrue"], atol=1e-8)
+    cal.close()
+
+
 def test_homography_lm_on_device_vs_reference():
     """calib_refine_homographies against the reference's _refineHomographies output (golden g7) and the
     batched host implementation."""

@@ -36,8 +36,23 @@ def test_c3_full_size_properties(c3):
     assert MN == 2_000_000
     eng = cca.RefineEngine("fisheye", "f64")
     eng.setProblem(offs, s, m)
-    # (1) zero error at the truth (tests/test_calibrate.py:123-133 at scale)
+    assert eng.fusedForm()[0] > 0                      # the headline shape runs in the stream form of the fused kernel
+    # (1) zero error at the truth (tests/test_calibrate.py:123-133 at scale). The shard's sensor points are projections
+    # made by the device itself (synthetic.makeShard), so this alone would be circular: the C ORACLE projects a sample of
+    # views, and those are what the device must agree with and have zero error against
     assert eng.evaluate(Ptrue)["sse"] < 1e-18 * MN
+    from oracle import c_oracle
+    if c_oracle.available():
+        views = np.concatenate((np.arange(0, 300), np.arange(4850, 5150), np.arange(9700, 10000)))
+        oo = np.arange(views.shape[0] + 1, dtype=np.int64) * 200
+        idx = (views[:, None] * 200 + np.arange(200)[None, :]).ravel()
+        Pv = np.concatenate((Ptrue[:L], Ptrue[L:].reshape(-1, 6)[views].ravel()))
+        yo = c_oracle.evaluate(orc.FISHEYE, Pv, oo, None, m[idx])["y"]
+        assert np.abs(yo - s[idx]).max() < 1e-9        # oracle-projected == device-projected sensor points
+        e2 = cca.RefineEngine("fisheye", "f64")
+        e2.setProblem(oo, yo, m[idx])
+        assert e2.evaluate(Pv)["sse"] < 1e-18 * idx.shape[0]
+        e2.close()
     # (2) first-order consistency of projection and Jacobian along a random direction
     rng = np.random.default_rng(1)
     d = rng.standard_normal(P0.shape[0]) * np.maximum(np.abs(P0), 1e-2) * 1e-3
@@ -563,3 +578,73 @@ def test_stream_form_of_the_fused_kernel(name, model, board, views, waves, monke
     n = min(5, b[7], trO.shape[0])
     assert np.array_equal(b[8][:n, 3], trO[:n, 3]) and np.allclose(b[8][:n, 1:3], trO[:n, 1:3], rtol=1e-9)
     assert relIntr(b[6], PO, L) < 1e-7
+
+
+def test_c3_slice_vs_c_oracle_default_forms(monkeypatch):
+    """The headline shape -- 200-point fisheye views -- against the C oracle on the same inputs, once with the form the
+    host picks for a 500-view shard (one view per wave, 4x4x4 blocks) and once in the stream form the full 10 000-view
+    shard runs in (same wave shares as there: 2.44 views per wave): normal equations, one step, the LM path."""
+    from oracle import c_oracle
+    if not c_oracle.available():
+        pytest.skip("oracle/libcalib_oracle.so not built")
+    sh = synthetic.makeShard("c3", viewStart=3000, numViews=500, noiseSigma=0.1)
+    offs, s, m, P0 = sh["viewOffsets"], sh["sensorPoints"], sh["modelPoints"], sh["P0"]
+    L = 9
+    do = c_oracle.step(orc.FISHEYE, P0, offs, s, m, 1e-3)
+    sseO, PO, trO = c_oracle.refine(orc.FISHEYE, P0, offs, s, m, 15)
+    eo = c_oracle.evaluate(orc.FISHEYE, P0, offs, s, m, wantJ=True)
+    Bo, Eo, Vo, go = orc.normalBlocks(orc.FISHEYE, eo["Jc"], eo["r"], offs)
+    for stream, waves in (("0", "0"), ("1", "205")):               # 500 views x 50 groups / 205 waves = 122 groups per wave
+        monkeypatch.setenv("CALIB_FUSED_STREAM", stream)
+        monkeypatch.setenv("CALIB_STREAM_WAVES", waves)
+        eng = cca.RefineEngine("fisheye", "f64")
+        eng.setProblem(offs, s, m)
+        assert (eng.fusedForm()[0] > 0) == (stream == "1")
+        B, E, V, g = eng.normalEquations(P0)
+        assert np.abs(B - Bo).max() <= 1e-11 * np.abs(Bo).max() and np.abs(V - Vo).max() <= 1e-11 * np.abs(Vo).max()
+        assert np.abs(E - Eo).max() <= 1e-11 * np.abs(Eo).max() and np.abs(g - go).max() <= 1e-10 * np.abs(go).max()
+        d = eng.stepDelta(P0, 1e-3)
+        assert np.linalg.norm(d - do) <= 1e-8 * np.linalg.norm(do)
+        sse, P, iters, trace = eng.refine(P0, 15)
+        assert abs(sse - sseO) <= 1e-8 * sseO and relIntr(P, PO, L) < 1e-7
+        n = min(5, iters, trO.shape[0])
+        assert np.array_equal(trace[:n, 3], trO[:n, 3]) and np.allclose(trace[:n, 1:3], trO[:n, 1:3], rtol=1e-9)
+        eng.close()
+
+
+def test_whole_c5_problem_on_one_gpu_properties():
+    """configs[4] WHOLE: 1 000 000 views x 88 points = 88 M correspondences resident on one GPU (3.5 GB), noise-free,
+    through size-independent properties: zero error at the generating parameters, accepted steps lower the error and
+    lambda follows the /10 - x10 rule, the generating intrinsics are recovered, a second refinement does not move
+    the result, and the shared block is the sum of the eight per-GPU shards' blocks (what the all-reduce adds up)."""
+    views = 1000000
+    sh = synthetic.makeShard("c5", numViews=views, noiseSigma=0.0)
+    offs, s, m, Ptrue, P0 = sh["viewOffsets"], sh["sensorPoints"], sh["modelPoints"], sh["Ptrue"], sh["P0"]
+    L, MN = 10, int(offs[-1])
+    assert MN == 88_000_000
+    eng = cca.RefineEngine("radtan", "f64")
+    eng.setProblem(offs, s, m)
+    assert eng.fusedForm()[0] > 0
+    assert eng.evaluate(Ptrue)["sse"] < 1e-18 * MN
+    sse, P, iters, trace = eng.refine(P0, 30)
+    acc = trace[:, 4] == 1
+    assert acc.sum() >= 3 and np.all(trace[acc, 2] < trace[acc, 1])
+    lam = trace[:, 3]
+    assert np.all(np.isclose(lam[1:], np.where(acc[:-1], lam[:-1] / 10, lam[:-1] * 10), rtol=1e-12))
+    assert relIntr(P, Ptrue, L) < 1e-9, relIntr(P, Ptrue, L)
+    sse2, P2, _, _ = eng.refine(P, 3)
+    assert np.abs(P2[:L] - P[:L]).max() < 1e-9
+    B, E, V, g = eng.normalEquations(P0)
+    eng.close()
+    Bsum = np.zeros_like(B)
+    per = views // 8
+    for r in range(8):
+        a, b = int(offs[r * per]), int(offs[(r + 1) * per])
+        e2 = cca.RefineEngine("radtan", "f64")
+        e2.setProblem(offs[r * per:(r + 1) * per + 1] - a, s[a:b], m[a:b])
+        Br, _, Vr, _ = e2.normalEquations(np.concatenate((P0[:L], P0[L + 6 * r * per:L + 6 * (r + 1) * per])))
+        e2.close()
+        Bsum += Br
+        if r in (0, 5):
+            assert np.all(np.abs(Vr - V[r * per:(r + 1) * per]).max(axis=(1, 2)) <= 1e-13 * np.abs(Vr).max(axis=(1, 2)))
+    assert np.abs(Bsum - B).max() <= 1e-12 * np.abs(B).max()

@@ -19,6 +19,7 @@ G5  200 ragged views x <=54 pts: P0, dense delta, Schur inputs (g5k: the same at
 G6  synthetic-generator poses for the bench boards (src/dataset.py:59-95)
 G7  DLT homographies and their LM polish (src/linearcalibrate.py:7-58, src/calibrate.py:60-115)
 G8  HomographyJacobian.compute and the mathutils helpers exp/skew/unskew/stack/unstack/project/projectStandard
+G9  tests/itest_main.py:31-52 noisy radtan calibration: detections (noise model), start point, LM trace, final A, k
 """
 import argparse
 import os
@@ -191,6 +192,18 @@ def g4():
     ds = ref.dataset.createRealisticRadTanDataset()
     cal = ref.getCalibrator("radtan")
     save("g4_realistic.npz", **_fullProblem(cal, ds, 100, "g4", False))
+
+
+def g9():
+    """tests/itest_main.py:31-52: the reference's NOISY radial-tangential calibration (sigma = 0.1 px; the noise is
+    drawn by src/noise.py:16 from the global generator src/dataset.py:64 re-seeds per view, after the pose draws)."""
+    A = np.array([[803.1, 0, 700.5], [0, 803.1, 529.2], [0, 0, 1]], dtype=np.float64)
+    k = (-0.25, 0.2, 0.07, -0.03, 0.05)
+    ds = ref.dataset.createSyntheticDatasetRadTan(A, 1440, 1080, k, ref.noise.NoiseModel(0.1))
+    cal = ref.getCalibrator("radtan")
+    arrays = _fullProblem(cal, ds, 100, "g9", False)
+    arrays.update(noiseSigma=np.float64(0.1), imageSize=np.array([1440, 1080], dtype=np.int64))
+    save("g9_noisy.npz", **arrays)
 
 
 def g5(M=200):
