@@ -1293,15 +1293,17 @@ __global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __r
                                                             const LMState* __restrict__ st,
                                                             const int* __restrict__ view_item0,
                                                             int nv, StreamMap sm, const double* __restrict__ bpart,
-                                                            int n_bpart, double* __restrict__ part) {
+                                                            int n_bpart, double* __restrict__ part, int only) {
     constexpr int VA = variantSize(L);
     constexpr int kNfail = 2 * L * L + 2 * L, kSse = kNfail + 1;
     __shared__ double sfail[kSchurViewsPerBlock];
     __shared__ double stile[kSchurBlock / 64][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = tid & 15, grp = tid >> 4, k = lane >> 4;
 
+    // only: -1 = everything; 0 = variant A and the sums; 1 = variant B alone (launched beside the pass over the points:
+    // the current blocks and the lambda it damps them with are known since the previous round's update)
     if (blockIdx.y == 2) {
-        if (st->done) return;
+        if (only == 1 || st->done) return;
         // thread t of each half-block owns one field of the workgroup partials of B, g_c, sum r^2
         constexpr int NF = L * L + L + 1;
         double* out = part + (int64_t)blockIdx.x * VA;
@@ -1344,6 +1346,7 @@ __global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __r
     const bool boot = st->round == 0;
     const int cand = st->cur ^ 1;
     const int variant = (int)blockIdx.y == cand ? 0 : 1;
+    if (only >= 0 && variant != only) return;
     double* out = part + ((int64_t)variant * gridDim.x + blockIdx.x) * VA;
     if (variant == 1 && boot) {       // no "current" blocks yet
         for (int i = tid; i < VA; i += kSchurBlock) out[i] = 0.0;

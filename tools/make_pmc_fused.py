@@ -4,7 +4,8 @@ profiles/<round>_<workload>_pmc.json from the counter passes of tools/pmc_pass.s
 
     python tools/make_pmc_fused.py --round r02 --workload c3 --tag c3 --batches 40000 --model fisheye
 
---batches = 64-lane batches one fused launch evaluates (views x ceil(points per view / 64)).
+--batches = 64-lane batches one fused launch evaluates (one view item per wave: views x ceil(points per view / 64);
+stream form: the sum over the waves of ceil(points of the wave's share / 64)).
 Counters are the mean over the dispatches of a kernel; FETCH_SIZE / WRITE_SIZE come in KiB, and on gfx950
 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read, so it is doubled (MI355X_MICROARCH.md, HBM)."""
 import argparse, csv, glob, json, os, subprocess
@@ -30,7 +31,7 @@ def collect(tag):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", default="r02")
+    ap.add_argument("--round", default="r03")
     ap.add_argument("--workload", required=True)
     ap.add_argument("--tag", required=True)
     ap.add_argument("--batches", type=int, required=True)
@@ -41,7 +42,7 @@ def main():
     out = os.path.join(ROOT, "profiles", f"{a.round}_{a.workload}_pmc.json")
     json.dump({"commit": commit, "command": f"tools/pmc_pass.sh {a.tag} (bench.py --steps 10, workload {a.workload})",
                "mean_per_dispatch": k}, open(out, "w"), indent=1, sort_keys=True)
-    fused = k.get("fused_kernel", {})
+    fused = k.get("fused_stream_kernel") or k.get("fused_kernel", {})
     jac = k.get("jacobian_kernel", {})
     f64 = 64.0 * (2 * fused.get("SQ_INSTS_VALU_FMA_F64", 0) + fused.get("SQ_INSTS_VALU_MUL_F64", 0)
                   + fused.get("SQ_INSTS_VALU_ADD_F64", 0) + fused.get("SQ_INSTS_VALU_TRANS_F64", 0)) / a.batches

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile refresh, run on the GPU box through gpurun:  bash tools/profile_round.sh
-# kernel-trace/stats and the PMC counters in separate passes; outputs under gpurun_out/, summarised into profiles/
+# kernel-trace/stats and the PMC counters in separate passes; outputs under gpurun_out/prof, summarised into profiles/
 # afterwards (tools/make_pmc_fused.py, cp of the *_kernel_stats.csv).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
@@ -11,8 +11,14 @@ for w in c3 c2 c4 c5; do
   find $R/gpurun_out/prof/stats_$w -name "*kernel_trace.csv" -delete      # the stats are what is kept (gpurun_out/ returns <= 64 MiB)
   echo "stats $w done"
 done
+# the driver's own command under the profiler: its fused-kernel average is what BENCH_rNN's roofline must agree with
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof/stats_c3_s20 -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof/stats_c3_s20.log 2>&1
+find $R/gpurun_out/prof/stats_c3_s20 -name "*kernel_trace.csv" -delete
+echo "stats c3 (driver flags) done"
 bash $R/tools/pmc_pass.sh c3
 bash $R/tools/pmc_pass.sh c5 --workload c5
+bash $R/tools/pmc_pass.sh c2 --workload c2
+bash $R/tools/pmc_pass.sh c4 --workload c4
 cd $R
 for w in c2 c4 c5; do
   python3 bench.py --workload $w --no-cpu-baseline > gpurun_out/prof/bench_$w.json 2> gpurun_out/prof/bench_$w.err
@@ -24,14 +30,23 @@ python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/prof/bench_c3_s20.j
 echo "bench c3 driver flags done"
 python3 bench.py > gpurun_out/prof/bench_c3.json 2> gpurun_out/prof/bench_c3.err
 echo "bench c3 done"
-# whole-chip fp64 pipe rates (tools/ubench/ubench6-8; binaries are built by hand, see the sources' headers)
-for u in ubench6 ubench7 ubench8 mfma4x4_layout; do
+CALIB_FUSED_STREAM=0 python3 bench.py --no-cpu-baseline > gpurun_out/prof/bench_c3_nostream.json 2> gpurun_out/prof/bench_c3_nostream.err
+CALIB_FUSED_STREAM=0 python3 bench.py --no-cpu-baseline --workload c5 > gpurun_out/prof/bench_c5_nostream.json 2> gpurun_out/prof/bench_c5_nostream.err
+echo "bench without the stream form done"
+# N ranks on ONE GPU over gloo (rehearsal of the N > 1 line: weak + strong blocks, every carrier)
+for n in 2 4; do
+  timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29700 + n)) \
+    bench.py --gpus $n --same-device --backend gloo --no-cpu-baseline --steps 20 --warmup 5 --min-seconds 0.2 > gpurun_out/prof/rehearsal_n$n.log 2>&1
+  grep "^{" gpurun_out/prof/rehearsal_n$n.log > gpurun_out/prof/rehearsal_n$n.json
+  echo "rehearsal n=$n done"
+done
+# whole-chip fp64 pipe rates (tools/ubench; binaries are built by hand, see the sources' headers)
+for u in ubench6 ubench7 ubench8 ubench10 mfma4x4_layout; do
   [ -x tools/ubench/$u ] && { echo "== $u"; tools/ubench/$u; } >> gpurun_out/prof/ubench.txt 2>&1
 done
 echo "ubench done"
-# per-phase stamps and in-situ ablation of the fused kernel (diagnostic builds: bash tools/diag/build_diag.sh first)
-if [ -f tools/diag/lib/stamps/libcalib_lm.so ]; then
-  { for a in "c3" "c5 125000" "c2" "c4 12500"; do python3 tools/diag/fused_stamps.py $a; done
-    for a in "c3" "c5 --views 125000" "c2" "c4 --views 12500"; do bash tools/diag/fused_ablation.sh $a; done; } 2>&1 | grep -vE "amdgpu.ids" > gpurun_out/prof/fused_diag.txt
-  echo "fused diag done"
+# per-phase stamps of the stream kernel (diagnostic build: bash tools/diag/build_stream_stamps.sh first)
+if [ -f tools/diag/lib/stream_stamps/libcalib_lm.so ]; then
+  { python3 tools/diag/stream_stamps.py c3; python3 tools/diag/stream_stamps.py c5 125000; } 2>&1 | grep -vE "amdgpu.ids" > gpurun_out/prof/stream_stamps.txt
+  echo "stream stamps done"
 fi
