@@ -4,6 +4,7 @@
 #include "kernels.hpp"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -186,20 +187,26 @@ namespace {
 
 size_t tsize(const calib_handle_s* h) { return h->dtype == CALIB_DTYPE_F64 ? 8 : 4; }
 
-int prof_begin(calib_handle_s* h, int kind) {
+// Profiled launches (calib_profile_enable): every prof_stride-th launch of a kernel kind gets a HIP event pair that
+// rides on the kernel's own dispatch (hipExtLaunchKernelGGL: the events take the kernel's begin and end timestamps).
+// Recording stream markers around the launch instead put two more packets into the queue, kept the launch from
+// being dispatched back to back with its neighbours and read ~3 us long on a 45 us kernel.
+int prof_reserve(calib_handle_s* h, int kind) {
     if (!h->prof || h->ev_used + 2 > h->ev.size()) return -1;
-    // the event pair around a launch keeps it from being dispatched back to back with its
-    // neighbours (c3: 12 us per LM round when every launch is timed), so only every
-    // prof_stride-th launch of a kind is bracketed
     if (h->prof_seen[kind]++ % h->prof_stride != 0) return -1;
     int idx = (int)h->ev_used;
     h->ev_used += 2;
     h->ev_kind[idx / 2] = kind;
-    (void)hipEventRecord(h->ev[idx], h->stream);
     return idx;
 }
-void prof_end(calib_handle_s* h, int idx) {
-    if (idx >= 0) (void)hipEventRecord(h->ev[idx + 1], h->stream);
+
+template <typename F, typename... Args>
+void launch_kind(calib_handle_s* h, int kind, F kernel, dim3 grid, dim3 block, size_t shmem, Args... args) {
+    const int idx = prof_reserve(h, kind);
+    if (idx >= 0)
+        hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)shmem, h->stream, h->ev[(size_t)idx], h->ev[(size_t)idx + 1], 0, args...);
+    else
+        hipLaunchKernelGGL(kernel, grid, block, shmem, h->stream, args...);
 }
 
 // ---- RCCL, resolved at run time (calib_rccl_load) ------------------------------------------
@@ -308,10 +315,8 @@ int launch_jacobian_t(calib_handle_s* h, const double* P0, const double* P1, con
     a.y = wantY ? reinterpret_cast<T2*>(h->y.p) : nullptr;
     a.sse_part = wantSse ? h->sse_part.p : nullptr;
     const size_t lds = 32 + (size_t)h->max_views_per_tile * kViewStride * sizeof(T);
-    int pi = prof_begin(h, 0);
     const unsigned tiles = (unsigned)((p_end - p_begin + kTile - 1) / kTile);
-    hipLaunchKernelGGL((jacobian_kernel<MODEL, T>), dim3(tiles), dim3(kTile), lds, h->stream, a);
-    prof_end(h, pi);
+    launch_kind(h, 0, jacobian_kernel<MODEL, T>, dim3(tiles), dim3(kTile), lds, a);
     LAUNCHED(h, "jacobian_kernel");
     return CALIB_OK;
 }
@@ -339,12 +344,10 @@ int launch_gram_t(calib_handle_s* h, const LMState* st, int sel, int item0, int 
     if (item1 <= item0) return CALIB_OK;
     const int ipb = 4 / h->gram_wpi;       // items per workgroup
     const int blocks = (item1 - item0 + ipb - 1) / ipb;
-    int pi = prof_begin(h, 1);
-    hipLaunchKernelGGL((gram_kernel<T, C>), dim3(blocks), dim3(256), 0, h->stream,
-                       reinterpret_cast<const T2*>(h->J.p), reinterpret_cast<const T2*>(h->r.p),
-                       h->item_pt0.p, h->item_n.p, item0, item1, origin, h->gram_wpi, st, sel, h->G[0].p,
-                       h->G[1].p, h->bpart.p, h->n_bpart);
-    prof_end(h, pi);
+    launch_kind(h, 1, gram_kernel<T, C>, dim3(blocks), dim3(256), 0,
+                reinterpret_cast<const T2*>(h->J.p), reinterpret_cast<const T2*>(h->r.p),
+                (const int64_t*)h->item_pt0.p, (const int*)h->item_n.p, item0, item1, origin, h->gram_wpi, st, sel, h->G[0].p,
+                h->G[1].p, h->bpart.p, h->n_bpart);
     h->n_bpart += blocks;                  // the chunk's workgroups append their partials
     LAUNCHED(h, "gram_kernel");
     return CALIB_OK;
@@ -375,16 +378,15 @@ int launch_fused_t(calib_handle_s* h, const LMState* st, int sel) {
     }
     const int ipb = (4 / wpi) * ipw;
     const int blocks = (h->n_items + ipb - 1) / ipb;
-    int pi = prof_begin(h, 2);
     // fp64 items of more than two batches build J^T J from 4x4 blocks (v_mfma_f64_4x4x4_4b, symmetric half only;
     // c3 -4.5 %); shorter items stay on the 16x16x4 form, whose record goes to HBM straight from the accumulators
     // (one-batch items: c2 +4 % on the block form; two batches, c5: no difference)
     auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, h->stream, h->P[0].p,
-                           h->P[1].p, reinterpret_cast<const T2*>(h->uv.p), reinterpret_cast<const T2*>(h->XY.p),
-                           reinterpret_cast<const T*>(h->Z.p), reinterpret_cast<const T*>(h->VC.p), h->item_pt0.p,
-                           h->item_n.p, h->item_view.p, h->n_items, h->uniform_n, ipw, wpi, h->emit_tab.p, st, sel, h->G[0].p, h->G[1].p,
-                           h->bpart.p);
+        launch_kind(h, 2, kernel, dim3(blocks), dim3(256), 0, (const double*)h->P[0].p,
+                    (const double*)h->P[1].p, reinterpret_cast<const T2*>(h->uv.p), reinterpret_cast<const T2*>(h->XY.p),
+                    reinterpret_cast<const T*>(h->Z.p), reinterpret_cast<const T*>(h->VC.p), (const int64_t*)h->item_pt0.p,
+                    (const int*)h->item_n.p, (const int*)h->item_view.p, h->n_items, h->uniform_n, ipw, wpi,
+                    (const uint32_t*)h->emit_tab.p, st, sel, h->G[0].p, h->G[1].p, h->bpart.p);
     };
     if constexpr (sizeof(T) == 8) {
         if (g44) launch(fused_kernel<MODEL, T, 32, 4, true, false>);
@@ -394,7 +396,6 @@ int launch_fused_t(calib_handle_s* h, const LMState* st, int sel) {
         if (ipw > 1) launch(fused_kernel<MODEL, T, 32, 4, false, true>);
         else launch(fused_kernel<MODEL, T, 32, 4, false, false>);
     }
-    prof_end(h, pi);
     h->n_bpart = blocks;
     LAUNCHED(h, "fused_kernel");
     return CALIB_OK;
@@ -414,12 +415,11 @@ int num_records(const calib_handle_s* h) { return std::max(h->n_items, 1) + h->s
 template <int MODEL>
 int launch_fused_stream(calib_handle_s* h, const LMState* st, int sel) {
     const int blocks = (h->stream_waves + 3) / 4;
-    int pi = prof_begin(h, 2);
-    hipLaunchKernelGGL((fused_stream_kernel<MODEL>), dim3(blocks), dim3(256), 0, h->stream, h->P[0].p, h->P[1].p,
-                       reinterpret_cast<const double2*>(h->uv.p), reinterpret_cast<const double2*>(h->XY.p),
-                       reinterpret_cast<const double*>(h->Z.p), reinterpret_cast<const double*>(h->VC.p), h->uniform_n,
-                       h->nv, h->stream_share, h->emit_tab.p, h->stream_ops.p, st, sel, h->G[0].p, h->G[1].p, h->bpart.p);
-    prof_end(h, pi);
+    launch_kind(h, 2, fused_stream_kernel<MODEL>, dim3(blocks), dim3(256), 0, (const double*)h->P[0].p, (const double*)h->P[1].p,
+                reinterpret_cast<const double2*>(h->uv.p), reinterpret_cast<const double2*>(h->XY.p),
+                reinterpret_cast<const double*>(h->Z.p), reinterpret_cast<const double*>(h->VC.p), h->uniform_n,
+                h->nv, h->stream_share, (const uint32_t*)h->emit_tab.p, (const int16_t*)h->stream_ops.p, st, sel, h->G[0].p, h->G[1].p,
+                h->bpart.p);
     h->n_bpart = blocks;
     LAUNCHED(h, "fused_stream_kernel");
     return CALIB_OK;

@@ -18,6 +18,11 @@ def short(n):
 
 
 def collect(tag):
+    """mean per dispatch of every counter per kernel: from the compact file tools/pmc_compact.py wrote on the GPU box
+    (gpurun_out/prof/pmc_<tag>.json), else from the raw counter_collection.csv files"""
+    compact = os.path.join(ROOT, "gpurun_out", "prof", f"pmc_{tag}.json")
+    if os.path.exists(compact):
+        return json.load(open(compact))
     acc = {}
     for f in sorted(glob.glob(os.path.join(ROOT, f"gpurun_out/pmc_{tag}_*/**/*counter_collection.csv"), recursive=True)):
         per = {}

@@ -15,10 +15,11 @@ done
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof/stats_c3_s20 -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof/stats_c3_s20.log 2>&1
 find $R/gpurun_out/prof/stats_c3_s20 -name "*kernel_trace.csv" -delete
 echo "stats c3 (driver flags) done"
-bash $R/tools/pmc_pass.sh c3
-bash $R/tools/pmc_pass.sh c5 --workload c5
-bash $R/tools/pmc_pass.sh c2 --workload c2
-bash $R/tools/pmc_pass.sh c4 --workload c4
+for w in c3 c5 c2 c4; do
+  bash $R/tools/pmc_pass.sh $w --workload $w
+  python3 $R/tools/pmc_compact.py $w        # raw counter files are tens of MiB per pass: keep the means only
+  rm -f $R/gpurun_out/pmc_${w}_*.log
+done
 cd $R
 for w in c2 c4 c5; do
   python3 bench.py --workload $w --no-cpu-baseline > gpurun_out/prof/bench_$w.json 2> gpurun_out/prof/bench_$w.err

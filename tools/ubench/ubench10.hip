@@ -63,13 +63,20 @@ void run(const char* vname, int cus, double* out) {
         hipEventSynchronize(e1);
         float ms = 0;
         hipEventElapsedTime(&ms, e0, e1);
-        const double waves = (double)blocks * 4;
         // instructions issued per SIMD (4 waves): kinds 0, 1: 4 waves x 2 iters x (5 | 20); kinds 2, 3: half of each
         const double mfmaPerSimd = (kind == 0 ? 4.0 : (kind == 1 ? 0.0 : 2.0)) * 2 * iters * 5;
         const double valuPerSimd = (kind == 1 ? 4.0 : (kind == 0 ? 0.0 : 2.0)) * 2 * iters * 20;
-        printf("CUs %3d %-8s %-34s %9.1f us   %7.0f MFMA + %8.0f VALU per SIMD -> %6.1f ns per (5 MFMA + 20 VALU)\n", cus, vname,
-               names[kind], ms * 1e3, mfmaPerSimd, valuPerSimd, ms * 1e6 / (2.0 * 2 * iters));
-        (void)waves;
+        static double nsMfma = 0, nsValu = 0;              // per instruction and SIMD, from the two pure runs
+        const double ns = ms * 1e6;
+        if (kind == 0) nsMfma = ns / mfmaPerSimd;
+        if (kind == 1) nsValu = ns / valuPerSimd;
+        if (kind < 2)
+            printf("CUs %3d %-8s %-34s %9.1f us   %.2f ns per %s instruction and SIMD\n", cus, vname, names[kind], ms * 1e3,
+                   kind == 0 ? nsMfma : nsValu, kind == 0 ? "MFMA" : "VALU");
+        else
+            printf("CUs %3d %-8s %-34s %9.1f us   the same instructions one after the other: %9.1f us  (measured / serial = %.2f)\n",
+                   cus, vname, names[kind], ms * 1e3, (mfmaPerSimd * nsMfma + valuPerSimd * nsValu) * 1e-3,
+                   ns / (mfmaPerSimd * nsMfma + valuPerSimd * nsValu));
     }
 }
 
