@@ -19,6 +19,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 using namespace calib;
@@ -469,9 +470,13 @@ int launch_schur(calib_handle_s* h, const LMState* st, hipStream_t stream, int o
         hipLaunchKernelGGL(kernel, grid, dim3(kSchurBlock), 0, stream, h->G[0].p, h->G[1].p, st, view_items(h), h->nv,
                            stream_map(h), h->bpart.p, h->n_bpart, h->part.p, only);
     };
-    const bool wide = wide_heads(h);
-    if (h->L == 10) { if (wide) launch(schur_kernel<10, true>); else launch(schur_kernel<10, false>); }
-    else { if (wide) launch(schur_kernel<9, true>); else launch(schur_kernel<9, false>); }
+    const bool wide = wide_heads(h), strm = stream_rounds(h);
+    auto pick = [&](auto Lc) {
+        constexpr int LL = decltype(Lc)::value;
+        if (strm) { if (wide) launch(schur_kernel<LL, true, true>); else launch(schur_kernel<LL, false, true>); }
+        else { if (wide) launch(schur_kernel<LL, true, false>); else launch(schur_kernel<LL, false, false>); }
+    };
+    if (h->L == 10) pick(std::integral_constant<int, 10>{}); else pick(std::integral_constant<int, 9>{});
     LAUNCHED(h, "schur_kernel");
     return CALIB_OK;
 }
@@ -521,9 +526,13 @@ template <int L, typename T>
 int launch_update_backsub_t(calib_handle_s* h) {
     if (h->nv <= kUpdSmallViews) {
         const int blocks = std::max(1, (h->nv + kUpdViewsPerBlock - 1) / kUpdViewsPerBlock);    // one view per 16-lane group
-        hipLaunchKernelGGL((update_backsub_small_kernel<L, T>), dim3(blocks), dim3(kUpdThreads), 0, h->stream,
-                           h->G[0].p, h->G[1].p, st_cur(h), st_next(h), h->red, view_items(h), h->view_ext.p, h->nv,
-                           stream_map(h), h->P[0].p, h->P[1].p, h->trace.p, reinterpret_cast<T*>(h->VC.p));
+        auto launchSmall = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kUpdThreads), 0, h->stream,
+                               h->G[0].p, h->G[1].p, st_cur(h), st_next(h), h->red, view_items(h), h->view_ext.p, h->nv,
+                               stream_map(h), h->P[0].p, h->P[1].p, h->trace.p, reinterpret_cast<T*>(h->VC.p));
+        };
+        if (stream_rounds(h)) launchSmall(update_backsub_small_kernel<L, T, true>);
+        else launchSmall(update_backsub_small_kernel<L, T, false>);
         LAUNCHED(h, "update_backsub_small_kernel");
         return CALIB_OK;
     }
@@ -534,8 +543,8 @@ int launch_update_backsub_t(calib_handle_s* h) {
                            h->G[1].p, st_cur(h), st_next(h), h->red, view_items(h), h->view_ext.p, h->nv,
                            stream_map(h), h->P[0].p, h->P[1].p, h->trace.p, reinterpret_cast<T*>(h->VC.p));
     };
-    if (wide_heads(h)) launch(update_backsub_kernel<L, T, true>);
-    else launch(update_backsub_kernel<L, T, false>);
+    if (stream_rounds(h)) { if (wide_heads(h)) launch(update_backsub_kernel<L, T, true, true>); else launch(update_backsub_kernel<L, T, false, true>); }
+    else { if (wide_heads(h)) launch(update_backsub_kernel<L, T, true, false>); else launch(update_backsub_kernel<L, T, false, false>); }
     LAUNCHED(h, "update_backsub_kernel");
     return CALIB_OK;
 }

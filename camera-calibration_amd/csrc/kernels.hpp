@@ -1131,6 +1131,8 @@ __global__ __launch_bounds__(256, 4) void fused_stream_kernel(const double* __re
 // the view boundaries. The record of view v (n4 groups) is written by the wave that holds the view's first group; a
 // wave whose share starts strictly inside a view writes what it sums of that view to its own overflow record nv + w.
 // With share >= n4 at most one wave starts inside a view, so a view is one or two records, found by arithmetic.
+// The per-view kernels are instantiated with and without the second record (STREAM): the narrow-load forms sit at the
+// 128-VGPR limit of four workgroups per CU, and the extra loads spilled them for every shard that has no cut views.
 struct StreamMap { int share, n4, nv; };     // share == 0: the shard's records are not in stream form
 __device__ __forceinline__ int stream_extra_item(const StreamMap& sm, int v) {
     if (sm.share == 0) return -1;
@@ -1287,7 +1289,7 @@ __device__ __forceinline__ bool eliminate(double (&V)[21], const double (&b)[6],
 constexpr int kSchurBlock = 256;
 constexpr int kSchurViewsPerBlock = kSchurBlock / 16;
 
-template <int L, bool WIDE>
+template <int L, bool WIDE, bool STREAM>
 __global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __restrict__ G0,
                                                             const double* __restrict__ G1,
                                                             const LMState* __restrict__ st,
@@ -1340,7 +1342,7 @@ __global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __r
     if (v0 + grp < nv) {
         // view_item0 == nullptr: every view is a single item (item index == view index)
         const int v = v0 + grp, i0 = view_item0 ? view_item0[v] : v;
-        load_view_head<L, WIDE>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, stream_extra_item(sm, v), c, V, b);
+        load_view_head<L, WIDE>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, (STREAM ? stream_extra_item(sm, v) : -1), c, V, b);
     }
     if (st->done) return;
     const bool boot = st->round == 0;
@@ -1366,7 +1368,7 @@ __global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __r
         double rn[7];
         if (WIDE && more) {                                   // the next trip's seven rows: in flight during this elimination
             const int v = v0 + stride + grp, i0 = view_item0 ? view_item0[v] : v;
-            request_head_rows(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, stream_extra_item(sm, v), c, rn);
+            request_head_rows(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, (STREAM ? stream_extra_item(sm, v) : -1), c, rn);
         }
         if (live) {
             double invd[6];
@@ -1383,7 +1385,7 @@ __global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __r
                 expand_head_rows<L>(rn, c, V, b);
             } else {                                          // the next trip's heads, behind this trip's MFMAs
                 const int v = v0 + grp, i0 = view_item0 ? view_item0[v] : v;
-                load_view_head<L, false>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, stream_extra_item(sm, v), c, V, b);
+                load_view_head<L, false>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, (STREAM ? stream_extra_item(sm, v) : -1), c, V, b);
             }
         }
         // W^T W: K-slot k = this lane's view, six rows per view
@@ -1887,7 +1889,7 @@ __device__ __forceinline__ void finish_view(const double (&V)[21], const double 
     if (c < 2) dst[16 + c] = (T)(c == 0 ? o18[16] : o18[17]);
 }
 
-template <int L, typename T, bool WIDE>
+template <int L, typename T, bool WIDE, bool STREAM>
 __global__ __launch_bounds__(kSchurThreads, 4) void update_backsub_kernel(
         const double* __restrict__ G0, const double* __restrict__ G1, const LMState* __restrict__ st_in,
         LMState* __restrict__ st_out, const double* __restrict__ red, const int* __restrict__ view_item0,
@@ -1924,7 +1926,7 @@ __global__ __launch_bounds__(kSchurThreads, 4) void update_backsub_kernel(
     double rn[7];
     if (WIDE && v < nv) {
         const int i0 = view_item0 ? view_item0[v] : v;
-        request_head_rows(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, stream_extra_item(sm, v), c, rn);
+        request_head_rows(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, (STREAM ? stream_extra_item(sm, v) : -1), c, rn);
     }
     for (; v < nv; v += stride) {
         double V[21], b[6], invd[6], z[6];
@@ -1932,11 +1934,11 @@ __global__ __launch_bounds__(kSchurThreads, 4) void update_backsub_kernel(
             expand_head_rows<L>(rn, c, V, b);
             if (v + stride < nv) {                            // the next view's rows: in flight during this view's update
                 const int vn = v + stride, i0 = view_item0 ? view_item0[vn] : vn;
-                request_head_rows(G, i0, view_item0 ? view_item0[vn + 1] - i0 : 1, stream_extra_item(sm, vn), c, rn);
+                request_head_rows(G, i0, view_item0 ? view_item0[vn + 1] - i0 : 1, (STREAM ? stream_extra_item(sm, vn) : -1), c, rn);
             }
         } else {
             const int i0 = view_item0 ? view_item0[v] : v;
-            load_view_head<L, false>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, stream_extra_item(sm, v), c, V, b);
+            load_view_head<L, false>(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, (STREAM ? stream_extra_item(sm, v) : -1), c, V, b);
         }
         eliminate(V, b, lam, invd, z);
         finish_view<L, T>(V, invd, z, coef, c, v, view_ext, Pc, Pn, VC);
@@ -1954,7 +1956,7 @@ constexpr int kUpdViewWaves = 4;
 constexpr int kUpdThreads = 64 * (1 + kUpdViewWaves);
 constexpr int kUpdViewsPerBlock = kUpdViewWaves * 4;
 
-template <int L, typename T>
+template <int L, typename T, bool STREAM>
 __global__ __launch_bounds__(kUpdThreads) void update_backsub_small_kernel(
         const double* __restrict__ G0, const double* __restrict__ G1, const LMState* __restrict__ st_in,
         LMState* __restrict__ st_out, const double* __restrict__ red, const int* __restrict__ view_item0,
@@ -1994,7 +1996,7 @@ __global__ __launch_bounds__(kUpdThreads) void update_backsub_small_kernel(
         }
         if (v < nv) {
             const int i0 = view_item0 ? view_item0[v] : v;
-            load_view_head<L, false>(cur ? G1 : G0, i0, view_item0 ? view_item0[v + 1] - i0 : 1, stream_extra_item(sm, v), c, V, b);
+            load_view_head<L, false>(cur ? G1 : G0, i0, view_item0 ? view_item0[v + 1] - i0 : 1, (STREAM ? stream_extra_item(sm, v) : -1), c, V, b);
             eliminate(V, b, lam, invd, z);
         }
     }

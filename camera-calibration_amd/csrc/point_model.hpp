@@ -100,7 +100,8 @@ struct Shared {               // the L shared parameters, converted once per thr
 };
 
 // Distortion value + first derivatives at normalised (x, y).
-// dk[j] = (dxd/dk_j, dyd/dk_j).
+// dk[j] = (dxd/dk_j, dyd/dk_j) for the tangential coefficients (radtan p1, p2); for a RADIAL coefficient, whose
+// derivative is (x, y) f_j, both entries hold the factor f_j (jacobian_point multiplies (x, y) in once for all of them).
 template <int MODEL, typename T>
 __device__ __forceinline__ void distort(const T* __restrict__ k, T x, T y,
                                         T& xd, T& yd, T& xd_x, T& xd_y, T& yd_y,
@@ -118,11 +119,11 @@ __device__ __forceinline__ void distort(const T* __restrict__ k, T x, T y,
         xd_x = rad + T(2) * xx * drad + T(2) * p1 * y + T(6) * p2 * x;
         xd_y = T(2) * xy * drad + T(2) * p1 * x + T(2) * p2 * y;
         yd_y = rad + T(2) * yy * drad + T(6) * p1 * y + T(2) * p2 * x;
-        dkx[0] = x * r2;  dky[0] = y * r2;
-        dkx[1] = x * r4;  dky[1] = y * r4;
+        dkx[0] = r2;  dky[0] = r2;          // radial terms k1, k2, k3: the common factor f_j of (x, y) f_j
+        dkx[1] = r4;  dky[1] = r4;
+        dkx[4] = r6;  dky[4] = r6;
         dkx[2] = T(2) * xy;           dky[2] = r2 + T(2) * yy;
         dkx[3] = r2 + T(2) * xx;      dky[3] = T(2) * xy;
-        dkx[4] = x * r6;  dky[4] = y * r6;
     } else {
         const T k1 = k[0], k2 = k[1], k3 = k[2], k4 = k[3];
         // 1 / r from a clamped r^2: at r = 0 (a point on the optical axis) ir stays finite and r = r2 * ir = 0,
@@ -151,7 +152,7 @@ __device__ __forceinline__ void distort(const T* __restrict__ k, T x, T y,
         yd_y = s + y * y * sror;
         T p = thr * t2;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { dkx[j] = x * p; dky[j] = y * p; p *= t2; }
+        for (int j = 0; j < 4; ++j) { dkx[j] = p; dky[j] = p; p *= t2; }     // all four radial: the factor f_j
     }
 }
 
@@ -199,10 +200,21 @@ __device__ __forceinline__ void jacobian_point(const Shared<MODEL, T>& sp, const
     J[2].x = yd;   J[2].y = T(0);
     J[3].x = T(1); J[3].y = T(0);
     J[4].x = T(0); J[4].y = T(1);
+    // radial coefficients: d(xd, yd)/dk_j = (x, y) f_j, so (du, dv)/dk_j = (al x + ga y, be y) f_j -- two
+    // multiplications per column instead of five (distort<> hands back f_j for them); the tangential p1, p2 in full
+    {
+        const T ax = sp.al * x + sp.ga * y, by = sp.be * y;
 #pragma unroll
-    for (int j = 0; j < NK; ++j) {
-        J[5 + j].x = sp.al * dkx[j] + sp.ga * dky[j];
-        J[5 + j].y = sp.be * dky[j];
+        for (int j = 0; j < NK; ++j) {
+            const bool radial = MODEL == kFisheye || j < 2 || j == 4;
+            if (radial) {
+                J[5 + j].x = ax * dkx[j];
+                J[5 + j].y = by * dkx[j];
+            } else {
+                J[5 + j].x = sp.al * dkx[j] + sp.ga * dky[j];
+                J[5 + j].y = sp.be * dky[j];
+            }
+        }
     }
     // d(u,v)/d(x,y), pre-scaled by 1/Zc
     const T ux = (sp.al * xd_x + sp.ga * yd_x) * iz;
