@@ -39,6 +39,25 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 a
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_fused.json")
 
 
+def kernelSourcesDigest():
+    import hashlib
+    h = hashlib.sha256()
+    try:
+        for f in ("kernels.hpp", "point_model.hpp", "calib_lm.hip"):
+            h.update(open(os.path.join(ROOT, "camera-calibration_amd", "csrc", f), "rb").read())
+    except OSError:
+        return None
+    return h.hexdigest()[:16]
+
+
+def countersMatchBuild():
+    """do the quoted PMC counters (profiles/pmc_fused.json) come from the kernel sources of THIS tree?"""
+    try:
+        return json.load(open(PMC_FILE)).get("kernel_sources_sha256_16") == kernelSourcesDigest()
+    except Exception:
+        return None
+
+
 def measuredCounters(workload, model):
     """-> (valu fp64 flops per 64-lane batch or None, fused kernel HBM bytes per launch or None,
     jacobian kernel HBM bytes per launch or None, source string)"""
@@ -493,6 +512,7 @@ def main():
                         "frac_mfma_plus_valu_useful": (tfl(contractFlops + valuUseful) / peak) if valuUseful else None,
                         "hbm_frac": 5 * w * fusedPts / sec / 1e9 / HBM_PEAK_GBS,
                         "traffic": fusedTraffic, "traffic_source": pmcSource if fusedTraffic else None,
+                        "counters_are_of_this_build": countersMatchBuild(),
                         "mfma_flops_per_launch": contractFlops, "mfma_flops_executed_per_launch": mfmaExecuted,
                         "valu_fp64_flops_per_launch_live_points": valuUseful,
                         "valu_flops_source": pmcSource if valuPerBatch else "none: profiles/pmc_fused.json has no entry",

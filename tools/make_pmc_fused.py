@@ -34,6 +34,16 @@ def collect(tag):
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items() if not k.startswith("__amd")}
 
 
+def sourcesDigest():
+    """sha256 over the kernel sources: bench.py compares it with the build it runs, so that a line quoting counters of
+    another build says so (there is no .git on the GPU box to compare commits with)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels.hpp", "point_model.hpp", "calib_lm.hip"):
+        h.update(open(os.path.join(ROOT, "camera-calibration_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--round", default="r03")
@@ -55,6 +65,7 @@ def main():
     pf = os.path.join(ROOT, "profiles", "pmc_fused.json")
     d = json.load(open(pf)) if os.path.exists(pf) else {}
     src = f"profiles/{a.round}_{a.workload}_pmc.json @ {commit}"
+    d["kernel_sources_sha256_16"] = sourcesDigest()
     d[a.workload] = {"valu_f64_flops_per_batch": f64 or None, "fused_hbm_bytes_per_launch": traffic(fused),
                      "jacobian_hbm_bytes_per_launch": traffic(jac), "source": src,
                      "valu_instructions_per_batch": (fused.get("SQ_INSTS_VALU", 0) - fused.get("SQ_INSTS_MFMA", 0)) / a.batches}
