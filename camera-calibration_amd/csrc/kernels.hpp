@@ -934,6 +934,10 @@ __global__ __launch_bounds__(256, 4) void fused_stream_kernel(const double* __re
             d1v = __builtin_amdgcn_mfma_f64_4x4x4f64(ja.y, jb.y, d1v, 0, 0, 0);
             d2u = __builtin_amdgcn_mfma_f64_4x4x4f64(ha, hc, d2u, 0, 0, 0);
         };
+        // Stage A of the NEXT batch's per-point model (projection + distortion: the long dependent chains) can be run in
+        // slices between the groups of this batch's second pass: pst then holds it when the next batch begins
+        PointState<MODEL, T> pst;
+        bool havePst = false;
         SSTAMP(0);
         for (int q0 = p0; q0 < p1; q0 += 64) {
             const int qe = q0 + 64 < p1 ? q0 + 64 : p1;
@@ -963,7 +967,8 @@ __global__ __launch_bounds__(256, 4) void fused_stream_kernel(const double* __re
             T u, v;
             T2 Jc[C];
             if (!strad) {
-                jacobian_point<MODEL, T>(sp, vcs, xy.x, xy.y, z, u, v, Jc);
+                if (!havePst) jacobian_stage_a<MODEL, T>(sp, vcs, xy.x, xy.y, z, pst);
+                jacobian_stage_b<MODEL, T>(sp, vcs, pst, u, v, Jc);
             } else {
                 // two views: every lane reads the constants of its own from the staged pair
                 double* sv = svc[wave];
@@ -991,6 +996,7 @@ __global__ __launch_bounds__(256, 4) void fused_stream_kernel(const double* __re
             // the SGPRs of the view constants are free now: the next one-view batch's arrive during the contraction
             if (more && !strad2) scalarLoad(vfirst2);
             strad = strad2;
+            havePst = false;
             // chunk pairs through v_permlane32_swap: one full-width store per pair and pass (see fused_kernel)
             constexpr int NCH = C - 5 + 1;                      // columns 5..C-1 and the residual
             T2 ch[NCH];
@@ -1029,7 +1035,36 @@ __global__ __launch_bounds__(256, 4) void fused_stream_kernel(const double* __re
                 SSTAMP(4);
                 const int ng = (p1 - ps >= ROWS ? ROWS : p1 - ps) >> 2;   // groups of the pass (shares are whole groups)
                 const int jb = (vend - ps) >> 2;                // the group a new view starts with (>= ng: none here)
-                if (ng == ROWS / 4 && jb >= ROWS / 4) {
+                // (measured, round 3: c3 45.3 -> 62.1 us, c5 shard 230 -> 438 us. Stage A's 10 carried values and its
+                // temporaries on top of the accumulators and the operands in flight do not fit the 128 VGPRs of four waves
+                // per SIMD: 27-33 spilled registers, ~20 scratch reloads per batch. Kept behind a macro for the record.)
+#ifdef CALIB_STREAM_INTERLEAVE
+                constexpr bool kInterleave = true;
+#else
+                constexpr bool kInterleave = false;
+#endif
+                if (kInterleave && ng == ROWS / 4 && jb >= ROWS / 4 && half == 1 && more && !strad2) {
+                    // EXPERIMENT (off): a whole second pass inside one view, and a one-view batch next: stage A of the next
+                    // batch's points (their coordinates and their view's constants have arrived) runs in eight slices, one
+                    // behind each group's five MFMAs -- matrix and vector instructions of the SAME wave overlap (ubench10),
+                    // and the dependent chains of stage A (reciprocals, arctangent) fill the matrix instructions' shadow
+                    T2 ja = src[c], jbb = src[c1];
+                    double ha = h0[0], hc = h2[0];
+                    jacobian_stage_a<MODEL, T>(sp, vcs, xy_n.x, xy_n.y, z_n, pst, [&](int s) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        contract(ja, jbb, ha, hc);
+                        if (s + 1 < ROWS / 4) {
+                            ja = src[66 * (s + 1) + c]; jbb = src[66 * (s + 1) + c1];
+                            ha = h0[2 * 66 * (s + 1)]; hc = h2[2 * 66 * (s + 1)];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    havePst = true;
+#ifdef CALIB_STREAM_STAMPS
+                    asm volatile("" :: "v"(d0u), "v"(d0v), "v"(d1u), "v"(d1v), "v"(d2u));
+#endif
+                    SSTAMP(5);
+                } else if (ng == ROWS / 4 && jb >= ROWS / 4) {
                     // a whole pass inside one view: every address is the wave's constant base plus an immediate
                     // the operands of group s + 1 are requested before group s is contracted
                     T2 ja = src[c], jbb = src[c1];

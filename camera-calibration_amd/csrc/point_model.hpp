@@ -72,21 +72,39 @@ __device__ __forceinline__ double fma_sconst(double a, double b, double sc) {   
     return r;
 }
 
+// Stage hooks: the per-point model can be evaluated in slices with a caller's work between them (fused_stream_kernel
+// contracts one 4-point group of the previous batch per slice: an MFMA followed by independent VALU work of the SAME
+// wave overlaps, tools/ubench/ubench10). NoHook = straight through.
+struct NoHook {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+
 // atan(r) for r >= 0 given ir = 1 / r (any value when r == 0): t = min(r, 1/r) in [0, 1],
 // atan(t) = t P(t^2) with P the degree-19 interpolant of atan(sqrt z) / sqrt z at the Chebyshev nodes of
 // [0, 1] (coefficients computed with mpmath at 60 digits, max relative error 2.5e-16), pi/2 - atan(1/r) above 1.
-__device__ __forceinline__ double atan_pos(double r, double ir) {
+// hook(H0) and hook(H0 + 1) are called a third and two thirds of the way through the Horner chain.
+template <int H0, class Hook>
+__device__ __forceinline__ double atan_pos(double r, double ir, Hook&& hook) {
     const bool big = r > 1.0;
     const double t = big ? ir : r;
     const double z = t * t;
     double p = kAtanPoly[0];
 #pragma unroll
-    for (int j = 1; j < 19; ++j) p = fma_sconst(p, z, kAtanPoly[j]);
+    for (int j = 1; j < 19; ++j) {
+        p = fma_sconst(p, z, kAtanPoly[j]);
+        if (j == 6) hook(H0);
+        if (j == 12) hook(H0 + 1);
+    }
     p = __builtin_fma(p, z, 1.0);
     const double a = t * p;
     return big ? 1.5707963267948966 - a : a;
 }
-__device__ __forceinline__ float atan_pos(float r, float) { return atanf(r); }
+template <int H0, class Hook>
+__device__ __forceinline__ float atan_pos(float r, float, Hook&& hook) {
+    hook(H0);
+    hook(H0 + 1);
+    return atanf(r);
+}
 
 template <int MODEL, typename T>
 struct Shared {               // the L shared parameters, converted once per thread
@@ -99,20 +117,66 @@ struct Shared {               // the L shared parameters, converted once per thr
     }
 };
 
-// Distortion value + first derivatives at normalised (x, y).
-// dk[j] = (dxd/dk_j, dyd/dk_j) for the tangential coefficients (radtan p1, p2); for a RADIAL coefficient, whose
-// derivative is (x, y) f_j, both entries hold the factor f_j (jacobian_point multiplies (x, y) in once for all of them).
-template <int MODEL, typename T>
-__device__ __forceinline__ void distort(const T* __restrict__ k, T x, T y,
-                                        T& xd, T& yd, T& xd_x, T& xd_y, T& yd_y,
-                                        T (&dkx)[ModelTraits<MODEL>::NK],
-                                        T (&dky)[ModelTraits<MODEL>::NK]) {
+// Distortion in two steps. The CORE is the long dependent chains (radtan: the radial polynomial and its derivative;
+// fisheye: 1/r, the arctangent, the two polynomials in theta^2): a handful of values per point. The rest -- the
+// distorted point, its derivatives, the coefficient columns -- are a few independent products of them.
+template <int MODEL, typename T> struct DistortCore;
+template <typename T> struct DistortCore<kRadtan, T> { T r2, rad, drad; };
+template <typename T> struct DistortCore<kFisheye, T> { T s, sror, p, t2; };     // p = theta^3 / r (the k1 factor)
+
+// calls hook(2) .. hook(7), once each and in order, between slices of its arithmetic
+template <int MODEL, typename T, class Hook = NoHook>
+__device__ __forceinline__ void distort_core(const T* __restrict__ k, T x, T y, DistortCore<MODEL, T>& c,
+                                             Hook&& hook = Hook()) {
     const T r2 = x * x + y * y;
     if constexpr (MODEL == kRadtan) {
-        const T k1 = k[0], k2 = k[1], p1 = k[2], p2 = k[3], k3 = k[4];
+        const T k1 = k[0], k2 = k[1], k3 = k[4];
+        c.r2 = r2;
+        c.rad = T(1) + r2 * (k1 + r2 * (k2 + r2 * k3));
+        hook(2);
+        c.drad = k1 + r2 * (T(2) * k2 + T(3) * k3 * r2);
+        hook(3); hook(4); hook(5); hook(6); hook(7);
+    } else {
+        const T k1 = k[0], k2 = k[1], k3 = k[2], k4 = k[3];
+        // 1 / r from a clamped r^2: at r = 0 (a point on the optical axis) ir stays finite and r = r2 * ir = 0,
+        // so theta = 0 and everything below is finite; the r -> 0 limits are selected by the r2 test
+        const T tiny = sizeof(T) == 8 ? T(1e-300) : T(1e-30);
+        const T ir = fast_rsqrt(r2 > tiny ? r2 : tiny);
+        const T r = r2 * ir;
+        hook(2);
+        const T th = atan_pos<3>(r, ir, hook);           // hook(3), hook(4)
+        const T t2 = th * th;
+        const T poly = T(1) + t2 * (k1 + t2 * (k2 + t2 * (k3 + t2 * k4)));
+        hook(5);
+        const T gp = (T(1) + t2 * (T(3) * k1 + t2 * (T(5) * k2 + t2 * (T(7) * k3 + T(9) * k4 * t2))))
+                     * fast_rcp(T(1) + r2);
+        hook(6);
+        // s = theta poly / r, s_r / r = (g' - s) / r^2; analytic limits at r -> 0
+        // (the reference evaluates 0/0 = NaN exactly at r = 0, src/distortion.py:215).
+        T thr;
+        if (r2 < T(1e-16)) {                            // r < 1e-8
+            c.s = T(1); thr = T(1); c.sror = T(2) * k1 - T(2) / T(3);
+        } else {
+            thr = th * ir;
+            c.s = thr * poly;
+            c.sror = (gp - c.s) * ir * ir;
+        }
+        c.p = thr * t2;
+        c.t2 = t2;
+        hook(7);
+    }
+}
+
+// dk[j] = (dxd/dk_j, dyd/dk_j) for the tangential coefficients (radtan p1, p2); for a RADIAL coefficient, whose
+// derivative is (x, y) f_j, both entries hold the factor f_j (jacobian_stage_b multiplies (x, y) in once for all of them).
+template <int MODEL, typename T>
+__device__ __forceinline__ void distort_finish(const T* __restrict__ k, T x, T y, const DistortCore<MODEL, T>& c,
+                                               T& xd, T& yd, T& xd_x, T& xd_y, T& yd_y,
+                                               T (&dkx)[ModelTraits<MODEL>::NK], T (&dky)[ModelTraits<MODEL>::NK]) {
+    if constexpr (MODEL == kRadtan) {
+        const T p1 = k[2], p2 = k[3];
+        const T r2 = c.r2, rad = c.rad, drad = c.drad;
         const T r4 = r2 * r2, r6 = r4 * r2;
-        const T rad = T(1) + r2 * (k1 + r2 * (k2 + r2 * k3));
-        const T drad = k1 + r2 * (T(2) * k2 + T(3) * k3 * r2);
         const T xy = x * y, xx = x * x, yy = y * y;
         xd = rad * x + T(2) * p1 * xy + p2 * (r2 + T(2) * xx);
         yd = rad * y + p1 * (r2 + T(2) * yy) + T(2) * p2 * xy;
@@ -125,35 +189,25 @@ __device__ __forceinline__ void distort(const T* __restrict__ k, T x, T y,
         dkx[2] = T(2) * xy;           dky[2] = r2 + T(2) * yy;
         dkx[3] = r2 + T(2) * xx;      dky[3] = T(2) * xy;
     } else {
-        const T k1 = k[0], k2 = k[1], k3 = k[2], k4 = k[3];
-        // 1 / r from a clamped r^2: at r = 0 (a point on the optical axis) ir stays finite and r = r2 * ir = 0,
-        // so theta = 0 and everything below is finite; the r -> 0 limits are selected by the r2 test
-        const T tiny = sizeof(T) == 8 ? T(1e-300) : T(1e-30);
-        const T ir = fast_rsqrt(r2 > tiny ? r2 : tiny);
-        const T r = r2 * ir;
-        const T th = atan_pos(r, ir);
-        const T t2 = th * th;
-        const T poly = T(1) + t2 * (k1 + t2 * (k2 + t2 * (k3 + t2 * k4)));
-        const T gp = (T(1) + t2 * (T(3) * k1 + t2 * (T(5) * k2 + t2 * (T(7) * k3 + T(9) * k4 * t2))))
-                     * fast_rcp(T(1) + r2);
-        // s = theta poly / r, s_r / r = (g' - s) / r^2; analytic limits at r -> 0
-        // (the reference evaluates 0/0 = NaN exactly at r = 0, src/distortion.py:215).
-        T s, sror, thr;
-        if (r2 < T(1e-16)) {                            // r < 1e-8
-            s = T(1); thr = T(1); sror = T(2) * k1 - T(2) / T(3);
-        } else {
-            thr = th * ir;
-            s = thr * poly;
-            sror = (gp - s) * ir * ir;
-        }
-        xd = s * x;  yd = s * y;
-        xd_x = s + x * x * sror;
-        xd_y = x * y * sror;
-        yd_y = s + y * y * sror;
-        T p = thr * t2;
+        xd = c.s * x;  yd = c.s * y;
+        xd_x = c.s + x * x * c.sror;
+        xd_y = x * y * c.sror;
+        yd_y = c.s + y * y * c.sror;
+        T p = c.p;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { dkx[j] = p; dky[j] = p; p *= t2; }     // all four radial: the factor f_j
+        for (int j = 0; j < 4; ++j) { dkx[j] = p; dky[j] = p; p *= c.t2; }     // all four radial: the factor f_j
     }
+}
+
+// Distortion value + first derivatives at normalised (x, y).
+template <int MODEL, typename T>
+__device__ __forceinline__ void distort(const T* __restrict__ k, T x, T y,
+                                        T& xd, T& yd, T& xd_x, T& xd_y, T& yd_y,
+                                        T (&dkx)[ModelTraits<MODEL>::NK],
+                                        T (&dky)[ModelTraits<MODEL>::NK]) {
+    DistortCore<MODEL, T> c;
+    distort_core<MODEL, T>(k, x, y, c);
+    distort_finish<MODEL, T>(k, x, y, c, xd, yd, xd_x, xd_y, yd_y, dkx, dky);
 }
 
 // Forward projection only (candidate-error style evaluation).
@@ -171,25 +225,41 @@ __device__ __forceinline__ void project_point(const Shared<MODEL, T>& sp, const 
     v = sp.be * yd + sp.vc;
 }
 
-// Projection + the point's 2 x C Jacobian block, J[c] = (du/dp_c, dv/dp_c) (one 16-byte pair per
-// column: what the HBM layout and the LDS transpose move). Column order is the reference's
-// (src/jacobian.py:22-26): [alpha beta gamma uc vc | k.. | rx ry rz tx ty tz].
+// What the first half of the per-point model hands to the second: the projection and the distortion core (stage A:
+// long dependent chains -- reciprocal, reciprocal square root, arctangent, polynomials); stage B forms the distorted
+// point, (u, v) and the 2 x C block from it (wide, independent products).
 template <int MODEL, typename T>
-__device__ __forceinline__ void jacobian_point(const Shared<MODEL, T>& sp, const T* __restrict__ vc,
-                                               T X, T Y, T Z, T& u, T& v,
-                                               typename Pair<T>::type (&J)[ModelTraits<MODEL>::C]) {
+struct PointState {
+    T x, y, iz, q0, q1, q2;
+    DistortCore<MODEL, T> core;
+};
+
+// calls hook(0) .. hook(7), once each and in order
+template <int MODEL, typename T, class Hook = NoHook>
+__device__ __forceinline__ void jacobian_stage_a(const Shared<MODEL, T>& sp, const T* __restrict__ vc, T X, T Y, T Z,
+                                                 PointState<MODEL, T>& st, Hook&& hook = Hook()) {
+    st.q0 = vc[0] * X + vc[1] * Y + vc[2] * Z;
+    st.q1 = vc[3] * X + vc[4] * Y + vc[5] * Z;
+    st.q2 = vc[6] * X + vc[7] * Y + vc[8] * Z;
+    const T Xc = st.q0 + vc[9], Yc = st.q1 + vc[10], Zc = st.q2 + vc[11];
+    hook(0);
+    st.iz = fast_rcp(Zc);
+    st.x = Xc * st.iz;
+    st.y = Yc * st.iz;
+    hook(1);
+    distort_core<MODEL, T>(sp.k, st.x, st.y, st.core, hook);
+}
+
+template <int MODEL, typename T>
+__device__ __forceinline__ void jacobian_stage_b(const Shared<MODEL, T>& sp, const T* __restrict__ vc,
+                                                 const PointState<MODEL, T>& st, T& u, T& v,
+                                                 typename Pair<T>::type (&J)[ModelTraits<MODEL>::C]) {
     constexpr int NK = ModelTraits<MODEL>::NK;
     constexpr int L = ModelTraits<MODEL>::L;
-    const T q0 = vc[0] * X + vc[1] * Y + vc[2] * Z;
-    const T q1 = vc[3] * X + vc[4] * Y + vc[5] * Z;
-    const T q2 = vc[6] * X + vc[7] * Y + vc[8] * Z;
-    const T Xc = q0 + vc[9], Yc = q1 + vc[10], Zc = q2 + vc[11];
-    const T iz = fast_rcp(Zc);
-    const T x = Xc * iz, y = Yc * iz;
-
+    const T x = st.x, y = st.y, iz = st.iz, q0 = st.q0, q1 = st.q1, q2 = st.q2;
     T xd, yd, xd_x, xd_y, yd_y;
     T dkx[NK], dky[NK];
-    distort<MODEL, T>(sp.k, x, y, xd, yd, xd_x, xd_y, yd_y, dkx, dky);
+    distort_finish<MODEL, T>(sp.k, x, y, st.core, xd, yd, xd_x, xd_y, yd_y, dkx, dky);
     const T yd_x = xd_y;
 
     u = sp.al * xd + sp.ga * yd + sp.uc;
@@ -240,6 +310,18 @@ __device__ __forceinline__ void jacobian_point(const Shared<MODEL, T>& sp, const
     J[L + 3].x = ux;  J[L + 3].y = vx;
     J[L + 4].x = uy;  J[L + 4].y = vy;
     J[L + 5].x = -(ux * x + uy * y);  J[L + 5].y = -(vx * x + vy * y);
+}
+
+// Projection + the point's 2 x C Jacobian block, J[c] = (du/dp_c, dv/dp_c) (one 16-byte pair per
+// column: what the HBM layout and the LDS transpose move). Column order is the reference's
+// (src/jacobian.py:22-26): [alpha beta gamma uc vc | k.. | rx ry rz tx ty tz].
+template <int MODEL, typename T>
+__device__ __forceinline__ void jacobian_point(const Shared<MODEL, T>& sp, const T* __restrict__ vc,
+                                               T X, T Y, T Z, T& u, T& v,
+                                               typename Pair<T>::type (&J)[ModelTraits<MODEL>::C]) {
+    PointState<MODEL, T> st;
+    jacobian_stage_a<MODEL, T>(sp, vc, X, Y, Z, st);
+    jacobian_stage_b<MODEL, T>(sp, vc, st, u, v, J);
 }
 
 }  // namespace calib
