@@ -14,7 +14,8 @@ buffer), accept/reject + L x L solve, back-substitution. Termination tests are d
 with full work. `value` is WEAK scaling (every rank holds `views` views of the config); at N > 1 the line also
 carries a `strong` block -- the config's GLOBAL problem (c3: 10 000 views, c5: 1 000 000) split N ways -- and, in
 `exchange`, the same K steps timed with every carrier of the per-round sum that passes its self-test (the library's
-own ncclAllReduce, torch.distributed.all_reduce, the in-kernel peer exchange); `value` is taken with RCCL.
+own ncclAllReduce, torch.distributed.all_reduce; with `--allreduce all` also the in-kernel peer exchange); `value` is
+taken with RCCL.
 One JSON line is printed by rank 0.
 """
 import argparse
@@ -167,13 +168,14 @@ def main():
     ap.add_argument("--scaling", choices=["both", "weak", "strong"], default="both",
                     help="N > 1: 'weak' = every rank holds the config's per-GPU views (this is `value`); 'strong' = the "
                          "config's global problem split N ways (block `strong`); 'both' (default) measures the two")
-    ap.add_argument("--allreduce", choices=["auto", "peer", "direct", "torch"], default="auto",
+    ap.add_argument("--allreduce", choices=["auto", "all", "peer", "direct", "torch"], default="auto",
                     help="the one exchange per LM step at N > 1. 'direct': ncclAllReduce issued by the library on its own "
                          "stream; 'torch': torch.distributed.all_reduce on the bound buffer; 'peer': the reduce kernel itself "
                          "sums over the ranks, point-to-point over xGMI through IPC-mapped slot memory (no collective "
-                         "launch). 'auto' (default) times every one of them whose start-up self-test passes on EVERY rank "
-                         "(block `exchange`) and takes `value` with RCCL: direct if it came up, else torch. The peer exchange "
-                         "has been exercised with several processes on one GPU only: opt-in for `value`")
+                         "launch). 'auto' (default) times the two RCCL carriers -- every one whose start-up self-test passes on "
+                         "EVERY rank (block `exchange`) -- and takes `value` with direct if it came up, else torch. 'all' adds the "
+                         "peer exchange to `exchange`: it has been exercised with several processes on ONE GPU only, so the "
+                         "default run of an 8-GPU node does not stake its line on it")
     ap.add_argument("--lm-mode", default="fused", choices=["fused", "two_kernel"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
@@ -249,7 +251,7 @@ def main():
         def engine():
             return spare.pop() if spare else makeEngine(shard)[0]
 
-        if want in ("auto", "direct") and args.backend == "nccl":
+        if want in ("auto", "all", "direct") and args.backend == "nccl":
             e = engine()
             ar = distributed.directAllReduce(e)
             if ar is not None:
@@ -258,11 +260,11 @@ def main():
                 spare.append(e)
                 if want == "direct":
                     sys.exit("bench.py --allreduce direct: the in-library all-reduce could not be set up")
-        if want in ("auto", "torch"):
+        if want in ("auto", "all", "torch"):
             e = engine()
             out.append(Carrier("torch", e, distributed.ShardedLM(e, distributed.torchAllReduce(e, devTorch)),
                                "torch.distributed.all_reduce"))
-        if want in ("auto", "peer") and world > 1:
+        if want in ("all", "peer") and world > 1:
             e = engine()
             ar = distributed.peerExchange(e)
             if ar is not None:
@@ -556,7 +558,8 @@ def main():
                                                                         else "exact sums of rank-dependent values over all ranks, against a deadline, passed on every rank"),
                        "lm_mode": args.lm_mode},
             "exchange": None if dist is None else {"ms_per_step": exchange, "what": "the same K steps of the weak block with every "
-                                                   "carrier of the per-round sum that passed its self-test on every rank",
+                                                   "carrier of the per-round sum that passed its self-test on every rank "
+                                                   "(the peer exchange only with --allreduce all | peer)",
                                                    "backend": args.backend},
             "strong": strong,
             "roofline": mainRoof,

@@ -37,7 +37,7 @@ echo "bench without the stream form done"
 # N ranks on ONE GPU over gloo (rehearsal of the N > 1 line: weak + strong blocks, every carrier)
 for n in 2 4; do
   timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29700 + n)) \
-    bench.py --gpus $n --same-device --backend gloo --no-cpu-baseline --steps 20 --warmup 5 --min-seconds 0.2 > gpurun_out/prof/rehearsal_n$n.log 2>&1
+    bench.py --gpus $n --same-device --backend gloo --allreduce all --no-cpu-baseline --steps 20 --warmup 5 --min-seconds 0.2 > gpurun_out/prof/rehearsal_n$n.log 2>&1
   grep "^{" gpurun_out/prof/rehearsal_n$n.log > gpurun_out/prof/rehearsal_n$n.json
   echo "rehearsal n=$n done"
 done
