@@ -185,6 +185,12 @@ def main():
                     help="rehearsal: drive the sharded (all-reduce per round) path even with one rank")
     args = ap.parse_args()
 
+    # stdout carries ONE JSON line. Libraries write there too (RCCL prints a version banner at communicator
+    # creation): everything up to the line goes to stderr, at file-descriptor level.
+    sys.stdout.flush()
+    stdoutFd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -594,7 +600,10 @@ def main():
                 out["cpu_baseline"] = cpuBaseline(shard, args.workload)
             except Exception as e:
                 out["cpu_baseline"] = {"error": str(e)}
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(stdoutFd, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     for c in carriers:
         c.eng.close()
     if not carriers:
