@@ -134,7 +134,7 @@ struct calib_handle_s {
     DevBuf<unsigned char> uv, XY, Z, VC, J, r, y;   // typed by dtype
     DevBuf<int> pt_view, view_ext, item_n, view_item0, item_view;
     DevBuf<uint32_t> emit_tab;    // fused kernel's record assembly table (buildEmitTable)
-    DevBuf<int16_t> stream_ops;   // fused_stream_kernel's per-lane record offsets (buildStreamOps)
+    DevBuf<int32_t> stream_ops;   // fused_stream_kernel's per-lane record offsets (buildStreamOps)
     int lm_mode = CALIB_LM_FUSED;
     int num_cus = 256;
     DevBuf<int64_t> item_pt0;
@@ -419,7 +419,7 @@ int launch_fused_stream(calib_handle_s* h, const LMState* st, int sel) {
     launch_kind(h, 2, fused_stream_kernel<MODEL>, dim3(blocks), dim3(256), 0, (const double*)h->P[0].p, (const double*)h->P[1].p,
                 reinterpret_cast<const double2*>(h->uv.p), reinterpret_cast<const double2*>(h->XY.p),
                 reinterpret_cast<const double*>(h->Z.p), reinterpret_cast<const double*>(h->VC.p), h->uniform_n,
-                h->nv, h->stream_share, (const uint32_t*)h->emit_tab.p, (const int16_t*)h->stream_ops.p, st, sel, h->G[0].p, h->G[1].p,
+                h->nv, h->stream_share, (const uint32_t*)h->emit_tab.p, (const int32_t*)h->stream_ops.p, st, sel, h->G[0].p, h->G[1].p,
                 h->bpart.p);
     h->n_bpart = blocks;
     LAUNCHED(h, "fused_stream_kernel");
@@ -621,7 +621,7 @@ int calib_create(int model, int dtype, int device_id, calib_handle_t* out_handle
         }
     }
     {
-        int16_t ops[64 * kStreamOps];
+        int32_t ops[64 * kStreamOps];
         const bool built = buildStreamOps(h->C, ops);
         e = built ? h->stream_ops.alloc(64 * kStreamOps) : hipErrorUnknown;
         if (e == hipSuccess) e = hipMemcpy(h->stream_ops.p, ops, sizeof(ops), hipMemcpyHostToDevice);

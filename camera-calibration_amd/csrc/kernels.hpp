@@ -749,7 +749,7 @@ __device__ unsigned long long g_sstamps[kSStampWaves * kSStampSlots];
 //    a batch that straddles a boundary uses per-lane constants: lanes 0..35 fetch the 36 doubles of the two views (one
 //    load, requested a batch ahead), stage them in 288 B of LDS, and every lane reads the 18 of its own view;
 //  * in the contraction, when the next group is the first of a new view, the finished view's record leaves STRAIGHT
-//    FROM THE ACCUMULATORS (no tile parking, no barrier): every lane knows from a table (buildStreamOps, 24 B per
+//    FROM THE ACCUMULATORS (no tile parking, no barrier): every lane knows from a table (buildStreamOps, 48 B per
 //    lane, kept in LDS) where in the 1 KiB record each of its block entries belongs -- once, or twice for an
 //    entry whose row AND column are view parameters -- and stores them there; the (b, b+2) blocks, whose u rows' and
 //    v rows' sums live in two different lanes, are completed with one ds_bpermute. Then everything that belongs
@@ -759,14 +759,15 @@ __device__ unsigned long long g_sstamps[kSStampWaves * kSStampSlots];
 //    the per-view kernels add the two). Only the entries the per-view kernels read are written: rows L..L+5 of
 //    J^T J and the view's six entries of J^T r (the record buffers are zeroed when they are allocated).
 // Everything else -- slab layout, chunk pairs, the five 4x4x4 instructions per group -- is fused_kernel's G44 form.
-constexpr int kStreamOps = 12;       // int16 byte offsets into the record per lane, -1 = nothing
+constexpr int kStreamOps = 12;       // byte offsets into the record per lane; kStreamNoOp (past the record) = nothing
+constexpr int kStreamNoOp = 0x7ffffff0;
 // op -> what is stored: 0, 1: d0u + d0v   2, 3: d1u + d1v   4, 5: d2 + the partner lane's d2
 //                       6: d0u  7: d0v  8: d1u  9: d1v  10: d2   (radial-tangential: the (1,1) column, see fused_kernel)
-inline bool buildStreamOps(int C, int16_t* ops /* 64 * kStreamOps */) {
+inline bool buildStreamOps(int C, int32_t* ops /* 64 * kStreamOps */) {
     uint32_t tab[kEmitTabSize];
     buildEmitTable(C, tab);
     const int L = C - 6;
-    for (int i = 0; i < 64 * kStreamOps; ++i) ops[i] = -1;
+    for (int i = 0; i < 64 * kStreamOps; ++i) ops[i] = kStreamNoOp;
     struct Src { int lane, acc; };          // acc: 0 d0u, 1 d0v, 2 d1u, 3 d1v, 4 d2
     const auto laneOf = [](int k, int b, int x) { return k * 16 + b * 4 + x; };
     // who holds entry idx = row * 16 + col of the u rows' (v rows') tile: see the block layout in fused_kernel
@@ -781,7 +782,7 @@ inline bool buildStreamOps(int C, int16_t* ops /* 64 * kStreamOps */) {
     bool ok = true;
     const auto put = [&](int lane, int first, int count, int slot) {
         for (int j = first; j < first + count; ++j)
-            if (ops[lane * kStreamOps + j] < 0) { ops[lane * kStreamOps + j] = (int16_t)(slot * 8); return; }
+            if (ops[lane * kStreamOps + j] == kStreamNoOp) { ops[lane * kStreamOps + j] = slot * 8; return; }
         ok = false;
     };
     for (int slot = 0; slot < kGHead; ++slot) {
@@ -812,7 +813,7 @@ __global__ __launch_bounds__(256, 4) void fused_stream_kernel(const double* __re
                                                               const double* __restrict__ Z, const double* __restrict__ VC,
                                                               int n, int nv, int share,
                                                               const uint32_t* __restrict__ emit_tab,
-                                                              const int16_t* __restrict__ stream_ops,
+                                                              const int32_t* __restrict__ stream_ops,
                                                               const LMState* __restrict__ st, int sel,
                                                               double* __restrict__ G0, double* __restrict__ G1,
                                                               double* __restrict__ part) {
@@ -825,7 +826,7 @@ __global__ __launch_bounds__(256, 4) void fused_stream_kernel(const double* __re
     auto rowOff = [](int r) { return r * 16 + (r >> 1); };
     __shared__ __attribute__((aligned(16))) unsigned char smem[WAVES * SLAB * sizeof(T2)];
     __shared__ __attribute__((aligned(16))) double svc[WAVES][2 * kViewStride];
-    __shared__ __attribute__((aligned(16))) int16_t sops[64 * kStreamOps];
+    __shared__ __attribute__((aligned(16))) int32_t sops[64 * kStreamOps];
     static_assert(SLAB * sizeof(T2) >= 2 * kEmitTile * 8, "tiles must fit the wave's slab");
 #ifdef CALIB_STREAM_STAMPS
     unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -849,32 +850,41 @@ __global__ __launch_bounds__(256, 4) void fused_stream_kernel(const double* __re
                keep2 = !(ofView(trow) || ofView(tcol2));
     // every wave writes the (same) whole table and every lane only ever reads back its own 24 bytes: no barrier
     {
-        const uint2* src = reinterpret_cast<const uint2*>(stream_ops) + 3 * lane;
-        uint2* dst = reinterpret_cast<uint2*>(sops) + 3 * lane;
+        const int4* src = reinterpret_cast<const int4*>(stream_ops) + 3 * lane;
+        int4* dst = reinterpret_cast<int4*>(sops) + 3 * lane;
         dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
     }
     const int partner = bj * 16 + ((bi + 2) & 3) * 4 + k;       // holds the other rows' sums of this lane's (b, b+2) entry
     // the finished view's record, straight from the accumulators; then what belongs to a view restarts from zero
+    // Every op is ONE buffer store with the lane's byte offset in the voffset: the record is a 1 KiB buffer resource, and
+    // an offset past it (kStreamNoOp: "this lane has nothing for this op") is dropped by the hardware's range check -- no
+    // compare, no branch, no address arithmetic (the first version unpacked int16 offsets and branched around 11 flat
+    // stores: ~70 vector instructions per view, 20 % of c5's).
     auto emitView = [&](int slot) {
-        char* G = reinterpret_cast<char*>(Gbase + (int64_t)slot * kGStride);
-        const uint2* o2 = reinterpret_cast<const uint2*>(sops) + 3 * lane;
-        const uint2 oa = o2[0], ob = o2[1];
+        typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+        const unsigned long long gp = reinterpret_cast<unsigned long long>(Gbase + (int64_t)slot * kGStride);
+        // (readfirstlane returns int: both halves through unsigned, or a set bit 31 of the low half smears into the high one)
+        const unsigned glo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)gp);
+        const unsigned ghi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(gp >> 32));
+        double* G = reinterpret_cast<double*>(((unsigned long long)ghi << 32) | (unsigned long long)glo);
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(G, 0, kGStride * 8, 0x00020000);
+        const int4* o4 = reinterpret_cast<const int4*>(sops) + 3 * lane;
+        const int4 oa = o4[0], ob = o4[1];
         const double s0 = d0u + d0v, s1 = d1u + d1v;
         const double dp = __hiloint2double(__builtin_amdgcn_ds_bpermute(partner << 2, __double2hiint(d2u)),
                                            __builtin_amdgcn_ds_bpermute(partner << 2, __double2loint(d2u)));
         const double s2 = d2u + dp;
-        auto put = [&](unsigned w, bool hi, double val) {
-            const int off = hi ? (int)w >> 16 : (int)(short)(w & 0xffffu);
-            if (off >= 0) *reinterpret_cast<double*>(G + off) = val;
+        auto put = [&](int off, double val) {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, val), rsrc, off, 0, 0);
         };
-        put(oa.x, false, s0); put(oa.x, true, s0);
-        put(oa.y, false, s1); put(oa.y, true, s1);
-        put(ob.x, false, s2); put(ob.x, true, s2);
+        put(oa.x, s0); put(oa.y, s0);
+        put(oa.z, s1); put(oa.w, s1);
+        put(ob.x, s2); put(ob.y, s2);
         if (ONES) {
-            const uint2 oc = o2[2];
-            put(ob.y, false, d0u); put(ob.y, true, d0v);
-            put(oc.x, false, d1u); put(oc.x, true, d1v);
-            put(oc.y, false, d2u);
+            const int4 oc = o4[2];
+            put(ob.z, d0u); put(ob.w, d0v);
+            put(oc.x, d1u); put(oc.y, d1v);
+            put(oc.z, d2u);
         }
         d0u = keep0 ? d0u : 0.0;  d0v = keep0 ? d0v : 0.0;
         d1u = keep1 ? d1u : 0.0;  d1v = keep1 ? d1v : 0.0;
