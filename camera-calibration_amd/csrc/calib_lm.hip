@@ -712,6 +712,12 @@ int calib_set_stream(calib_handle_t h, void* hip_stream, int use_own) {
     return CALIB_OK;
 }
 
+int calib_synchronize(calib_handle_t h) {
+    CHECK_H(h);
+    SYNC_H(h);
+    return CALIB_OK;
+}
+
 int calib_set_lm_mode(calib_handle_t h, int mode) {
     CHECK_H(h);
     if (mode != CALIB_LM_FUSED && mode != CALIB_LM_TWO_KERNEL) return fail(CALIB_E_INVALID, "unknown LM mode");

@@ -270,6 +270,10 @@ class RefineEngine:
     def lmAllReduce(self):
         nat.check(self._lib.calib_lm_allreduce(self._h))
 
+    def synchronize(self):
+        """wait for everything enqueued on the engine's stream (calib_synchronize)"""
+        nat.check(self._lib.calib_synchronize(self._h))
+
     def lmDone(self):
         d = ctypes.c_int(0)
         nat.check(self._lib.calib_lm_done(self._h, ctypes.byref(d)))

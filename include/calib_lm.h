@@ -66,6 +66,9 @@ int calib_destroy(calib_handle_t h);
  * (non-blocking) stream; otherwise hip_stream is used as given, NULL being the HIP default
  * stream (which is what torch.cuda.current_stream().cuda_stream is unless the caller changed it). */
 int calib_set_stream(calib_handle_t h, void* hip_stream, int use_own);
+/* Wait until everything enqueued on the handle's stream has run (hipStreamSynchronize); an asynchronous fault of an
+ * earlier launch is reported here with the names of the kernels enqueued since the last successful wait. */
+int calib_synchronize(calib_handle_t h);
 
 /* Upload the correspondences once (replaces getSensorPoints' vstack, src/calibrate.py:277-282).
  * sensor_uv: (MN,2) row-major as numpy, may be NULL (projection-only use);
