@@ -44,7 +44,7 @@ def kernelSourcesDigest():
     import hashlib
     h = hashlib.sha256()
     try:
-        for f in ("kernels.hpp", "point_model.hpp")      # the device code:
+        for f in ("kernels.hpp", "point_model.hpp"):      # the device code
             h.update(open(os.path.join(ROOT, "camera-calibration_amd", "csrc", f), "rb").read())
     except OSError:
         return None

@@ -39,7 +39,7 @@ def sourcesDigest():
     another build says so (there is no .git on the GPU box to compare commits with)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels.hpp", "point_model.hpp")      # the device code:
+    for f in ("kernels.hpp", "point_model.hpp"):      # the device code
         h.update(open(os.path.join(ROOT, "camera-calibration_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
