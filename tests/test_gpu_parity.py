@@ -694,3 +694,37 @@ def test_c_program_against_the_header(tmp_path):
     assert np.allclose(A, g["Afinal"], atol=1e-9) and np.allclose(k, g["kfinal"], atol=1e-9)
     assert np.abs(W - g["Wfinal"]).max() < 1e-8
     assert P.shape[0] == 10 + 6 * M and np.abs(P[:10] - g["Pfinal"][:10]).max() < 1e-9
+
+
+def test_fused_form_and_synchronize_entry_points(monkeypatch):
+    """calib_fused_form says which form of the fused kernel a loaded problem's rounds run in (the stream form needs
+    uniform fp64 views of whole 4-point groups, at least one batch long; the default also wants two views per wave
+    slot, CALIB_FUSED_STREAM=1 lifts that); calib_synchronize is a plain wait on the handle's stream."""
+    g = loadGolden("g2_config1_radtan.npz")                       # 10 views x 54 points: never eligible
+    eng = makeEngine("radtan", g)
+    assert eng.fusedForm() == (0, 0)
+    eng.lmBegin(g["P0"], 5)
+    eng.lmRun(3)
+    eng.synchronize()
+    assert eng.lmEnd()[2] >= 1
+    eng.close()
+    sh = synthetic.makeShard(dict(synthetic.CONFIGS["c5"]), numViews=40, noiseSigma=0.0)
+    for env, want in ((None, False), ("1", True), ("0", False)):
+        if env is None:
+            monkeypatch.delenv("CALIB_FUSED_STREAM", raising=False)
+        else:
+            monkeypatch.setenv("CALIB_FUSED_STREAM", env)
+        e2 = cca.RefineEngine("radtan", "f64")
+        e2.setProblem(sh["viewOffsets"], sh["sensorPoints"], sh["modelPoints"])
+        share, waves = e2.fusedForm()
+        assert (share > 0) == want
+        if want:
+            assert waves >= 1 and share * waves >= 40 * 22 and share >= 22      # every group dealt out; a share >= one view
+            e2.setLmMode("two_kernel")
+            assert e2.fusedForm() == (0, 0)                                     # the two-kernel rounds write one record per item
+        e2.close()
+    f32 = cca.RefineEngine("radtan", "f32")
+    monkeypatch.setenv("CALIB_FUSED_STREAM", "1")
+    f32.setProblem(sh["viewOffsets"], sh["sensorPoints"], sh["modelPoints"])
+    assert f32.fusedForm() == (0, 0)                                            # fp32 storage keeps one view per wave
+    f32.close()
