@@ -648,3 +648,16 @@ def test_whole_c5_problem_on_one_gpu_properties():
         if r in (0, 5):
             assert np.all(np.abs(Vr - V[r * per:(r + 1) * per]).max(axis=(1, 2)) <= 1e-13 * np.abs(Vr).max(axis=(1, 2)))
     assert np.abs(Bsum - B).max() <= 1e-12 * np.abs(B).max()
+
+
+def test_stream_form_boundary_stress():
+    """tools/stress_stream.py, 60 random (points per view, views, launch width) cases: wave cuts at every position,
+    batches straddling at every group, one-view shares, single waves -- the stream form against the one-view-per-wave
+    forms, normal equations to 1e-12 and the LM step to 1e-9."""
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_stream.py"), "60", "3"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ok: 60 cases" in r.stdout
