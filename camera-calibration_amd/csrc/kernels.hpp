@@ -2,7 +2,9 @@
 //
 // One LM round on one shard (launch order in calib_lm.hip: calib_lm_local / calib_lm_update):
 //   fused            per view item: residuals + 2xC Jacobian blocks in registers -> LDS transpose ->
-//                    16x16 J^T J, J^T r, sum r^2 via v_mfma_f64_16x16x4_f64        [fp64-ALU-bound]
+//                    16x16 J^T J, J^T r, sum r^2 via v_mfma_f64_16x16x4_f64 / 4x4x4 blocks   [fp64-ALU-bound]
+//     (fused_stream  the same for large uniform fp64 shards: equal shares of 4-point groups per wave, batches across
+//                    view boundaries, records straight from the accumulators)
 //     (two-kernel mode instead: jacobian -> compact J in HBM -> gram               [HBM-bound])
 //   schur            per view: 6x6 Cholesky elimination; sum E Vh^-1 [E^T|g] = W^T W via MFMA
 //   reduce           fixed-order sum of block partials -> reduce buffer (all-reduced across shards)
