@@ -40,12 +40,20 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 a
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_fused.json")
 
 
+def codeOnly(text):
+    """C++ source without // comments, /* */ comments and white space: what a digest of 'the same kernels' should see"""
+    import re
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    return re.sub(r"\s+", "", text)
+
+
 def kernelSourcesDigest():
     import hashlib
     h = hashlib.sha256()
     try:
-        for f in ("kernels.hpp", "point_model.hpp"):      # the device code
-            h.update(open(os.path.join(ROOT, "camera-calibration_amd", "csrc", f), "rb").read())
+        for f in ("kernels.hpp", "point_model.hpp"):      # the device code, comments and white space aside
+            h.update(codeOnly(open(os.path.join(ROOT, "camera-calibration_amd", "csrc", f)).read()).encode())
     except OSError:
         return None
     return h.hexdigest()[:16]

@@ -39,8 +39,12 @@ def sourcesDigest():
     another build says so (there is no .git on the GPU box to compare commits with)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels.hpp", "point_model.hpp"):      # the device code
-        h.update(open(os.path.join(ROOT, "camera-calibration_amd", "csrc", f), "rb").read())
+    import re
+    for f in ("kernels.hpp", "point_model.hpp"):      # the device code, comments and white space aside (as bench.py)
+        text = open(os.path.join(ROOT, "camera-calibration_amd", "csrc", f)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        h.update(re.sub(r"\s+", "", text).encode())
     return h.hexdigest()[:16]
 
 
