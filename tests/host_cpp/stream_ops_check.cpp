@@ -1,0 +1,49 @@
+// Host-side check of the tables the fused kernels assemble a view's record with (kernels.hpp: buildEmitTable,
+// buildStreamOps). Compiled and run by tests/test_host_cpu.py with hipcc; only host functions run -- no GPU needed:
+//  * every record entry the per-view kernels read -- the six view rows of J^T J and the view's six entries of J^T r --
+//    is stored by exactly ONE (lane, op) of the stream form's direct emission, nothing else is stored, and every
+//    offset is either inside the 1 KiB record or the "no op" offset the buffer range check drops;
+//  * an op's source matches the table entry it serves: a sum of both row kinds (ops 0-5) exactly where the emit table
+//    adds the u tile and the v tile at the same index, a single part (ops 6-10) where it picks one.
+#include "../../camera-calibration_amd/csrc/kernels.hpp"
+#include <cstdio>
+#include <map>
+#include <set>
+
+using namespace calib;
+
+static int check(int C) {
+    const int L = C - 6;
+    uint32_t tab[kEmitTabSize];
+    buildEmitTable(C, tab);
+    int32_t ops[64 * kStreamOps];
+    if (!buildStreamOps(C, ops)) { std::printf("C=%d: buildStreamOps reports an inconsistency\n", C); return 1; }
+    std::set<int> wanted;
+    for (int slot = 0; slot < kGHead; ++slot) {
+        const bool read = slot < kGg || (slot >= kGg + L && slot < kGg + L + 6);
+        const int iu = (int)(tab[slot] & 0xffff), iv = (int)(tab[slot] >> 16);
+        if (read && !(iu == kEmitZero && iv == kEmitZero)) wanted.insert(slot);
+    }
+    std::map<int, int> writers;
+    int bad = 0;
+    for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < kStreamOps; ++j) {
+            const int off = ops[lane * kStreamOps + j];
+            if (off == kStreamNoOp) continue;
+            if (off < 0 || off >= kGStride * 8 || (off & 7)) { std::printf("C=%d lane %d op %d: offset %d\n", C, lane, j, off); ++bad; continue; }
+            const int slot = off / 8;
+            writers[slot] += 1;
+            if (!wanted.count(slot)) { std::printf("C=%d lane %d op %d stores slot %d nobody reads\n", C, lane, j, slot); ++bad; }
+            const int iu = (int)(tab[slot] & 0xffff), iv = (int)(tab[slot] >> 16);
+            const bool both = iu != kEmitZero && iv != kEmitZero;
+            if (both != (j < 6)) { std::printf("C=%d lane %d op %d (slot %d): source kind does not match the emit table\n", C, lane, j, slot); ++bad; }
+            if (j == 11) { std::printf("C=%d lane %d uses the spare op 11\n", C, lane); ++bad; }
+            if (C == 15 && j >= 6) { std::printf("C=15 lane %d uses single-part op %d (the kernel skips them for fisheye)\n", lane, j); ++bad; }
+        }
+    for (int slot : wanted)
+        if (writers[slot] != 1) { std::printf("C=%d: slot %d has %d writers\n", C, slot, writers[slot]); ++bad; }
+    std::printf("C=%d: %zu record entries, each stored by exactly one lane: %s\n", C, wanted.size(), bad ? "FAILED" : "ok");
+    return bad;
+}
+
+int main() { return (check(15) + check(16)) ? 1 : 0; }

@@ -155,3 +155,17 @@ def test_injected_jacobian_is_refused_before_anything_runs():
     with pytest.raises(TypeError, match="injected Jacobian"):
         cal.refineCalibrationParameters(g["A0"], list(g["W0"]), tuple(g["k0"]), dets, 2)
     cal._jac.compute.assert_not_called()
+
+
+def test_record_emission_tables_cover_every_read_entry_once(tmp_path):
+    """The stream form of the fused kernel stores a view's record straight from the block accumulators through a per-lane
+    table (kernels.hpp: buildStreamOps). tests/host_cpp/stream_ops_check.cpp runs the table builders on the HOST and
+    checks, for both models, that every record entry the per-view kernels read is stored by exactly one lane, nothing
+    else is stored, and the source kind of each op matches the emit table."""
+    import subprocess
+    exe = tmp_path / "stream_ops_check"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "--offload-arch=gfx950", "-w", "-o", str(exe),
+                    os.path.join(ROOT, "tests", "host_cpp", "stream_ops_check.cpp")], check=True, capture_output=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "C=15: 96 record entries" in out.stdout and "C=16: 102 record entries" in out.stdout
