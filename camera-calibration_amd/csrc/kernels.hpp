@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(256, 4) void fused_stream_kernel(const double* __re
 // The per-view kernels are instantiated with and without the second record (STREAM): the narrow-load forms sit at the
 // 128-VGPR limit of four workgroups per CU, and the extra loads spilled them for every shard that has no cut views.
 struct StreamMap { int share, n4, nv; };     // share == 0: the shard's records are not in stream form
-__device__ __forceinline__ int stream_extra_item(const StreamMap& sm, int v) {
+__host__ __device__ __forceinline__ int stream_extra_item(const StreamMap& sm, int v) {
     if (sm.share == 0) return -1;
     const unsigned first = (unsigned)v * (unsigned)sm.n4, last = first + (unsigned)sm.n4 - 1u;
     const unsigned w = last / (unsigned)sm.share;             // the wave that holds the view's last group

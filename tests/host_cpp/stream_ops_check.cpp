@@ -46,4 +46,29 @@ static int check(int C) {
     return bad;
 }
 
-int main() { return (check(15) + check(16)) ? 1 : 0; }
+// stream_extra_item (which overflow record, if any, holds the part of view v a second wave summed) against a direct
+// simulation of the wave cuts: wave w starts at group w * share; a start strictly inside a view cuts that view.
+static int checkCuts() {
+    int bad = 0, cases = 0;
+    for (int n4 = 16; n4 <= 128; n4 += (n4 < 32 ? 1 : 7))
+        for (int nv = 1; nv <= 70; nv += (nv < 12 ? 1 : 9))
+            for (int waves = 1; waves <= nv; ++waves) {
+                const long long groups = (long long)nv * n4;
+                const int share = (int)((groups + waves - 1) / waves);
+                std::map<int, int> extra;
+                for (long long w = 1; w * share < groups; ++w)
+                    if ((w * share) % n4 != 0) extra[(int)(w * share / n4)] = nv + (int)w;
+                StreamMap sm; sm.share = share; sm.n4 = n4; sm.nv = nv;
+                for (int v = 0; v < nv; ++v) {
+                    const int want = extra.count(v) ? extra[v] : -1, got = stream_extra_item(sm, v);
+                    if (want != got) { if (bad < 10) std::printf("n4=%d nv=%d waves=%d share=%d view %d: %d, simulation %d\n", n4, nv, waves, share, v, got, want); ++bad; }
+                }
+                ++cases;
+            }
+    StreamMap off; off.share = 0; off.n4 = 50; off.nv = 10;
+    if (stream_extra_item(off, 3) != -1) ++bad;
+    std::printf("wave cuts: %d (views per group count, views, waves) cases: %s\n", cases, bad ? "FAILED" : "ok");
+    return bad;
+}
+
+int main() { return (check(15) + check(16) + checkCuts()) ? 1 : 0; }

@@ -169,3 +169,6 @@ def test_record_emission_tables_cover_every_read_entry_once(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "C=15: 96 record entries" in out.stdout and "C=16: 102 record entries" in out.stdout
+    # ... and stream_extra_item (which overflow record holds the rest of a view cut by a wave start) agrees with a
+    # direct simulation of the cuts on a few thousand (groups per view, views, waves) combinations
+    assert "wave cuts:" in out.stdout and out.stdout.rstrip().endswith("ok")
