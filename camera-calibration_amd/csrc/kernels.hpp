@@ -371,12 +371,16 @@ __global__ __launch_bounds__(256) void gram_kernel(const typename Pair<T>::type*
 // FMA-only waves make no progress while a SIMD mate streams fp64 MFMAs), so the kernel's floor is the sum of
 // its matrix and vector issue time; a producer / consumer split of the waves and a persistent-wave form were
 // both built and measured slower.
+// (second __launch_bounds__ argument = waves per SIMD the register allocator must leave room for. fp32 storage: the
+// kernel fits 80 VGPRs without a spill -- 6 waves per SIMD instead of 4 at 115 VGPRs: c4 shard 20.4 -> 18.9 us; 8 waves
+// spill and cost 30 %; the several-views-per-wave radtan form needs 94: 5 waves)
 constexpr int kFusedRowChunks = 17;                       // 16 columns + 1 pad chunk (odd => conflict-free)
 
 // ROWS = points transposed per LDS pass (32: two passes per 64-point batch, half the lanes
 // writing each time; 64: one pass, twice the LDS). WAVES = waves per workgroup.
 template <int MODEL, typename T, int ROWS, int WAVES, bool G44, bool MULTI>
-__global__ __launch_bounds__(64 * WAVES, (ModelTraits<MODEL>::C == 16 ? 4 : 3)) void fused_kernel(const double* __restrict__ P0, const double* __restrict__ P1,
+__global__ __launch_bounds__(64 * WAVES, (sizeof(T) == 4 ? ((MULTI && ModelTraits<MODEL>::C == 16) ? 5 : 6)
+                                                             : (ModelTraits<MODEL>::C == 16 ? 4 : 3))) void fused_kernel(const double* __restrict__ P0, const double* __restrict__ P1,
                                                     const typename Pair<T>::type* __restrict__ uv,
                                                     const typename Pair<T>::type* __restrict__ XY,
                                                     const T* __restrict__ Z, const T* __restrict__ VC,
