@@ -87,7 +87,7 @@ def algorithmicBytesPerPoint(L, wordBytes):
     return (7 + 2 * C) * wordBytes, (2 * C + 2) * wordBytes
 
 
-def cpuBaseline(shard, cfgName, seconds=20.0):
+def cpuBaseline(shard, cfgName, seconds=20.0, denseOnly=False):
     """The oracle (numpy restatement of the reference algorithm: dense J, dense J^T J, explicit
     inv) timed on this box's host cores, on a bounded sample of the same workload."""
     from oracle import calib_oracle as orc
@@ -114,7 +114,7 @@ def cpuBaseline(shard, cfgName, seconds=20.0):
     cPort = None
     try:
         from oracle import c_oracle
-        if c_oracle.available():
+        if c_oracle.available() and not denseOnly:
             # the C/OpenMP restatement (block-arrow / Schur form) on ALL host cores, on the whole shard
             full = (shard["viewOffsets"], shard["sensorPoints"], shard["modelPoints"])
             c_oracle.refine(model, shard["P0"], *full, 1, lamMin=0.0, lamMax=np.inf, errMin=-np.inf)    # threads up
@@ -166,7 +166,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100, help="LM iterations per timed segment (<= 100)")
-    ap.add_argument("--min-seconds", type=float, default=0.5,
+    ap.add_argument("--min-seconds", type=float, default=2.0,
                     help="the K-step segment is repeated until the timed phase lasts at least this long")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c3", help="c2 | c3 | c4 | c5 (BASELINE.json configs[1..4])")
@@ -189,6 +189,10 @@ def main():
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
                          "multi-rank path with several ranks on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--rccl-library", default=None,
+                    help="rehearsal: resolve the in-library carrier's ncclAllReduce from this library instead of PyTorch's "
+                         "librccl.so (tests/fake_rccl/librccl_standin.so lets several ranks share one GPU, which the real "
+                         "RCCL refuses); with it `--backend gloo --same-device --allreduce direct` drives rccl_direct")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: drive the sharded (all-reduce per round) path even with one rank")
     args = ap.parse_args()
@@ -208,6 +212,8 @@ def main():
         args.gpus = world
     # the host driver supports dmabuf IPC only: RCCL and the peer exchange need this in every rank's environment
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.rccl_library:
+        os.environ["CALIB_RCCL_LIBRARY"] = os.path.abspath(args.rccl_library)
 
     import torch
     import camera_calibration_amd as cca
@@ -265,7 +271,7 @@ def main():
         def engine():
             return spare.pop() if spare else makeEngine(shard)[0]
 
-        if want in ("auto", "all", "direct") and args.backend == "nccl":
+        if want in ("auto", "all", "direct") and (args.backend == "nccl" or args.rccl_library):
             e = engine()
             ar = distributed.directAllReduce(e)
             if ar is not None:
@@ -357,7 +363,7 @@ def main():
             tc = torch.tensor([tCal], dtype=torch.float64, device="cuda")
             dist.all_reduce(tc, op=dist.ReduceOp.MAX)
             tCal = float(tc.item())
-        R = int(min(301, max(5, np.ceil(minSeconds / max(tCal, 1e-6)))))
+        R = int(min(2001, max(5, np.ceil(minSeconds / max(tCal, 1e-6)))))
         R += 1 - R % 2                                         # odd: the median is one of the segments
         itersBefore = state["iters"]
         state["trace"] = []
@@ -603,9 +609,15 @@ def main():
             # (x10 each): the loop then ends early and later rounds are no-ops -- such a run is not a measurement
             print(f"bench: only {iters} of {total} LM iterations executed (lambda left the fp64 range); "
                   f"use fewer --steps", file=sys.stderr)
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # N = 1: the dense numpy sample and the C/OpenMP port on all host cores (~17 s). N > 1: rank 0 times the
+            # dense sample only (a few seconds, the other ranks wait in the closing barrier) -- the host's cores are
+            # shared by N ranks there, and the N = 1 line of the same node holds the full baseline.
             try:
-                out["cpu_baseline"] = cpuBaseline(shard, args.workload)
+                out["cpu_baseline"] = cpuBaseline(shard, args.workload, denseOnly=world > 1)
+                if world > 1:
+                    out["cpu_baseline"]["note"] = ("rank 0 only, dense sample only; the C/OpenMP port on all host cores is in "
+                                                   "the N = 1 line")
             except Exception as e:
                 out["cpu_baseline"] = {"error": str(e)}
         sys.stdout.flush()

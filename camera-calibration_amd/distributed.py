@@ -182,14 +182,23 @@ def peerExchange(eng, timeoutSeconds=60.0, selfTestRounds=64, selfTestTimeout=10
     return allReduce
 
 
-def directAllReduce(eng, timeoutSeconds=30.0):
+def rcclLibraryPath():
+    """librccl.so the in-library all-reduce resolves ncclAllReduce & co. from: the one PyTorch ships (and has already
+    loaded), unless CALIB_RCCL_LIBRARY names another build -- the GPU tests put tests/fake_rccl's stand-in there to
+    run several ranks on ONE device, which the real RCCL refuses."""
+    import os
+    import torch
+    return os.environ.get("CALIB_RCCL_LIBRARY") or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+
+
+def directAllReduce(eng, timeoutSeconds=30.0, libraryPath=None, initTimeoutSeconds=120.0):
     """Let the engine issue the all-reduce itself (ncclAllReduce on its own stream, RCCL resolved from
     the librccl.so PyTorch ships and has already loaded): no hand-off to the process group's stream,
-    and whole LM rounds run from C. The communicator is bootstrapped over the default process group;
-    before it is trusted it all-reduces a rank-dependent vector and checks the sums against a deadline.
+    and whole LM rounds run from C. The communicator is bootstrapped over the default process group (any backend:
+    only the 128-byte unique id travels over it); before it is trusted it all-reduces a rank-dependent vector and
+    checks the sums against a deadline.
     -> the all-reduce callable, or None when any rank could not set it up (the caller then uses
     torchAllReduce); every rank takes the same branch."""
-    import os
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -200,7 +209,7 @@ def directAllReduce(eng, timeoutSeconds=30.0):
 
     ok = True
     try:
-        eng.rcclLoad(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+        eng.rcclLoad(libraryPath or rcclLibraryPath())
     except Exception:
         ok = False
     if not allRanksOk(ok):
@@ -216,7 +225,7 @@ def directAllReduce(eng, timeoutSeconds=30.0):
         return None
     ok = True
     try:
-        eng.rcclInit(world, rank, ids[0])          # collective
+        eng.rcclInit(world, rank, ids[0], initTimeoutSeconds)          # collective
         eng.rcclSelfTest(timeoutSeconds)
     except Exception:
         ok = False
@@ -292,7 +301,9 @@ def refineDistributed(modelName, P0, viewOffsets, sensorPoints, modelPoints, max
         want = os.environ.get("CALIB_ALLREDUCE", "auto")
         if want == "peer" and world > 1:
             allReduce = peerExchange(eng)
-        if allReduce is None and want in ("direct", "auto", "peer") and dist.get_backend() == "nccl":
+        # (auto takes the in-library carrier only under the nccl backend: a gloo group means ranks that may share a
+        # device, where RCCL cannot come up; an explicit "direct" is tried under any backend)
+        if allReduce is None and (want == "direct" or (want in ("auto", "peer") and dist.get_backend() == "nccl")):
             allReduce = directAllReduce(eng)
         if allReduce is None:
             allReduce = torchAllReduce(eng, torch.device("cuda", eng.device))

@@ -3,8 +3,12 @@ itself), one rank each, all on GPU 0, through camera-calibration_amd/distributed
 default factories -- RefineEngine shards and, for the one exchange per LM round, either
 torch.distributed.all_reduce on the bound reduce buffer (carried by gloo: a single GPU cannot host several
 RCCL ranks) or the peer exchange inside the reduce kernel (calib_peer_*: IPC-mapped slot memory; here the
-"peers" are processes on the same card). The nccl binding itself is covered at world size 1, on both the
-torch and the in-library path. The parent plus at most 4 children use the card at once (the GPU boxes allow 6)."""
+"peers" are processes on the same card), or the library's own ncclAllReduce (calib_rccl_*: the DEFAULT carrier of a
+multi-GPU run) resolved from tests/fake_rccl's stand-in librccl -- the real RCCL refuses two ranks on one device, so
+the stand-in (shared-memory exchange behind the same five entry points, asynchronous and stream-ordered like the
+real one) is what lets that branch of calib_lm_run_sharded have more than one participant before an 8-GPU node does.
+The nccl binding itself is covered at world size 1, on both the torch and the in-library path. The parent plus at
+most 4 children use the card at once (the GPU boxes allow 6)."""
 import os
 import socket
 
@@ -14,6 +18,8 @@ import pytest
 from conftest import loadGolden
 
 pytestmark = pytest.mark.gpu
+
+STANDIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl", "librccl_standin.so")
 
 
 def _freePort():
@@ -33,9 +39,12 @@ def _problem(case):
             g["modelPoints"][:n], L)
 
 
-def _worker(rank, world, port, backend, case, allreduce, outDir):
+def _worker(rank, world, port, backend, case, allreduce, outDir, extraEnv=None, checkEvery=8):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0", RANK=str(rank),
                       WORLD_SIZE=str(world), CALIB_ALLREDUCE=allreduce, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if allreduce == "direct" and backend == "gloo":       # several ranks on one device: the stand-in librccl
+        os.environ["CALIB_RCCL_LIBRARY"] = STANDIN
+    os.environ.update(extraEnv or {})
     import torch
     import torch.distributed as dist
     from camera_calibration_amd import distributed
@@ -46,16 +55,19 @@ def _worker(rank, world, port, backend, case, allreduce, outDir):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         model, P0, offs, s, m, L = _problem(case)
-        sse, P, iters, trace = distributed.refineDistributed(model, P0, offs, s, m, 60)
+        sse, P, iters, trace = distributed.refineDistributed(model, P0, offs, s, m, 60, checkEvery=checkEvery)
         np.savez(os.path.join(outDir, f"r{rank}.npz"), sse=sse, P=P, iters=iters, trace=trace,
                  kind=distributed.refineDistributed.lastAllReduce)
     finally:
         dist.destroy_process_group()
 
 
-def _run(tmp_path, world, backend, case, allreduce="torch"):
+def _run(tmp_path, world, backend, case, allreduce="torch", extraEnv=None, checkEvery=8):
     import torch.multiprocessing as mp
-    mp.spawn(_worker, args=(world, _freePort(), backend, case, allreduce, str(tmp_path)), nprocs=world, join=True)
+    if allreduce == "direct" and backend == "gloo" and not os.path.exists(STANDIN):
+        pytest.fail(f"{STANDIN} is missing: __graft_entry__.build() (make -C tests/fake_rccl) builds it")
+    mp.spawn(_worker, args=(world, _freePort(), backend, case, allreduce, str(tmp_path), extraEnv, checkEvery),
+             nprocs=world, join=True)
     return [np.load(os.path.join(tmp_path, f"r{r}.npz")) for r in range(world)]
 
 
@@ -70,7 +82,9 @@ def _single(case):
 
 
 @pytest.mark.parametrize("world,case,allreduce", [(2, "g3", "torch"), (3, "g3", "torch"), (4, "fisheye3", "torch"),
-                                                  (2, "g3", "peer"), (3, "g3", "peer"), (4, "fisheye3", "peer")])
+                                                  (2, "g3", "peer"), (3, "g3", "peer"), (4, "fisheye3", "peer"),
+                                                  (2, "g3", "direct"), (3, "g3", "direct"), (4, "g3", "direct"),
+                                                  (4, "fisheye3", "direct")])
 def test_refine_distributed_real_engines_on_one_gpu(tmp_path, world, case, allreduce):
     outs = _run(tmp_path, world, "gloo", case, allreduce)
     (sseR, PR, itR, trR), L = _single(case)
@@ -92,6 +106,80 @@ def test_refine_distributed_real_engines_on_one_gpu(tmp_path, world, case, allre
     if case == "g3":                             # and the reference's own result
         g = loadGolden("g3_unittest15.npz")
         assert np.abs(P[:L] - g["Pfinal"][:L]).max() < 1e-9
+
+
+def test_in_library_allreduce_ranks_stop_together(tmp_path):
+    """calib_lm_run_sharded(check_every > 0) with several participants: g3 converges after 8 of the 60 allowed
+    iterations; looking at the (replicated) done flag every 2 rounds, every 8 rounds, or never must end every rank
+    on the same round with the same bits -- what src/calibrate.py:161-168 needs of a sharded run (one decision)."""
+    runs = {}
+    for ce in (2, 8, 0):
+        d = tmp_path / f"ce{ce}"
+        d.mkdir()
+        runs[ce] = _run(d, 3, "gloo", "g3", "direct", checkEvery=ce)
+    for ce, outs in runs.items():
+        for o in outs:
+            assert str(o["kind"]) == "direct"
+            assert int(o["iters"]) == int(runs[0][0]["iters"]) and np.array_equal(o["P"], runs[0][0]["P"]), ce
+            assert np.array_equal(o["trace"], runs[0][0]["trace"]), ce
+    g = loadGolden("g3_unittest15.npz")
+    assert np.abs(runs[2][0]["P"][:10] - g["Pfinal"][:10]).max() < 1e-9
+
+
+def test_in_library_allreduce_failed_selftest_falls_back_on_every_rank(tmp_path):
+    """Rank 1's start-up self-test sees a wrong sum (the stand-in corrupts that rank's first all-reduce): that rank
+    aborts its communicator, the MIN all-reduce of the ok flags makes EVERY rank drop the carrier, and the run goes
+    through torch.distributed.all_reduce -- same answer, nobody hangs (distributed.directAllReduce)."""
+    outs = _run(tmp_path, 3, "gloo", "g3", "direct", extraEnv={"CALIB_STANDIN_CORRUPT": "1:1"})
+    (sseR, PR, itR, trR), L = _single("g3")
+    for o in outs:
+        assert str(o["kind"]) == "torch"
+        assert np.array_equal(o["P"], outs[0]["P"]) and int(o["iters"]) == int(outs[0]["iters"])
+    assert np.abs(outs[0]["P"][:L] - PR[:L]).max() <= 1e-9 * max(1.0, np.abs(PR[:L]).max())
+
+
+def _joinWorker(rank, world, port, outDir):
+    """calib_rccl_* alone: a rank that never calls ncclCommInitRank must not hang the others."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      CALIB_STANDIN_JOIN_TIMEOUT="4")
+    import time
+    import torch.distributed as dist
+    import camera_calibration_amd as cca
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {"error": "", "seconds": 0.0, "allreduce_error": ""}
+    try:
+        eng = cca.RefineEngine("radtan", "f64")
+        eng.rcclLoad(STANDIN)
+        ids = [eng.rcclUniqueId() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        if rank != 1:
+            t0 = time.perf_counter()
+            try:
+                eng.rcclInit(world, rank, ids[0], 1.5)
+            except RuntimeError as e:
+                out["error"] = str(e)
+            out["seconds"] = time.perf_counter() - t0
+            try:                                          # and the handle has no communicator afterwards
+                eng.rcclSelfTest(1.0)
+            except RuntimeError as e:
+                out["allreduce_error"] = str(e)
+        dist.barrier()
+        time.sleep(3.5)          # let the abandoned ncclCommInitRank calls run into the stand-in's own timeout
+        eng.close()
+    finally:
+        np.savez(os.path.join(outDir, f"j{rank}.npz"), **out)
+        dist.destroy_process_group()
+
+
+def test_in_library_allreduce_missing_rank_meets_the_deadline(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_joinWorker, args=(3, _freePort(), str(tmp_path)), nprocs=3, join=True)
+    outs = [np.load(os.path.join(tmp_path, f"j{r}.npz")) for r in range(3)]
+    for r in (0, 2):
+        assert "did not return before the deadline" in str(outs[r]["error"])
+        assert 1.0 < float(outs[r]["seconds"]) < 4.0
+        assert "calib_rccl_init has not been called" in str(outs[r]["allreduce_error"])
+    assert str(outs[1]["error"]) == ""
 
 
 @pytest.mark.parametrize("allreduce", ["torch", "direct"])

@@ -29,6 +29,24 @@ def test_library_exports_every_declared_symbol():
     assert lib.calib_version() >= 100
 
 
+def test_rccl_standin_exports_what_the_library_resolves():
+    """tests/fake_rccl/librccl_standin.so (test infrastructure: several ranks on ONE GPU through the in-library
+    ncclAllReduce carrier) must offer exactly the entry points calib_rccl_load looks up (csrc/calib_lm.hip)."""
+    import ctypes
+    path = os.path.join(ROOT, "tests", "fake_rccl", "librccl_standin.so")
+    assert os.path.exists(path), "make -C tests/fake_rccl (done by __graft_entry__.build())"
+    lib = ctypes.CDLL(path)
+    for n in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllReduce", "ncclCommDestroy", "ncclCommAbort", "ncclGetErrorString"):
+        assert hasattr(lib, n), n
+    src = open(os.path.join(ROOT, "camera-calibration_amd", "csrc", "calib_lm.hip")).read()
+    assert sorted(set(re.findall(r'dlsym\(lib, "(nccl[A-Za-z]+)"\)', src))) == sorted(
+        ["ncclGetUniqueId", "ncclCommInitRank", "ncclAllReduce", "ncclCommDestroy", "ncclCommAbort", "ncclGetErrorString"])
+    ident = ctypes.create_string_buffer(128)
+    assert lib.ncclGetUniqueId(ident) == 0 and ident.raw.startswith(b"/calib_rccl_standin_")
+    lib.ncclGetErrorString.restype = ctypes.c_char_p
+    assert b"stand-in" in lib.ncclGetErrorString(2)
+
+
 def test_no_cpu_fallback_without_device():
     if nat.deviceCount() > 0:
         pytest.skip("a GPU is visible")
