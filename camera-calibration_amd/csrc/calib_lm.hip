@@ -889,7 +889,7 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
         const int un = h->uniform_n;
         const bool can = h->dtype == CALIB_DTYPE_F64 && un >= 64 && (un & 3) == 0 && MN < ((int64_t)1 << 31) && h->nv >= 1;
         if (can && h->stream_mode != 0) {
-            const int slots = h->stream_waves_env > 0 ? h->stream_waves_env : 16 * h->num_cus;
+            const int slots = h->stream_waves_env > 0 ? h->stream_waves_env : 4 * CALIB_STREAM_MIN_BLOCKS * h->num_cus;
             const int waves = std::max(1, std::min(slots, h->nv));
             if (h->stream_mode == 1 || h->nv >= 2 * slots) {
                 const int64_t groups = (int64_t)h->nv * (un / 4);
@@ -1528,9 +1528,9 @@ int calib_normal_eq(calib_handle_t h, const double* P, double* out_B, double* ou
                     for (int i = 0; i < kGStride; ++i) blk[i] += G[(size_t)(sm.nv + w) * kGStride + i];
             }
             for (int a = 0; a < 6; ++a) {
-                if (out_g) out_g[L + 6 * (int64_t)v + a] = blk[kGg + L + a];
-                for (int b = 0; b < 6; ++b)
-                    if (out_V) out_V[((int64_t)v * 6 + a) * 6 + b] = blk[kGRows + a * 16 + L + b];
+                if (out_g) out_g[L + 6 * (int64_t)v + a] = blk[gvSlot(L, a)];
+                for (int b = 0; b < 6; ++b)     // V is symmetric; the record holds its lower triangle (g_v rides in the upper)
+                    if (out_V) out_V[((int64_t)v * 6 + a) * 6 + b] = blk[kGRows + (a >= b ? a * 16 + L + b : b * 16 + L + a)];
                 for (int c = 0; c < L; ++c)
                     if (out_E) out_E[((int64_t)v * L + c) * 6 + a] = blk[kGRows + a * 16 + c];
             }

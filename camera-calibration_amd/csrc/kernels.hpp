@@ -23,14 +23,22 @@ constexpr int kGramUnroll = 4;    // 4-point groups (1 KiB wave-loads of J) in f
 // Normal equations of one pass over the points. With the parameter order (L shared, 6 view) the
 // 16x16 tile G = J^T J of a view item splits into the shared block B = G[0:L, 0:L] and the six view
 // rows R = G[L:L+6, 0:16] = [E^T | V | 0] (the E block above the diagonal is R's transpose).
-// * Per item, a 1 KiB record: R, then g = J^T r, then sum r^2 -- all the per-view elimination reads.
+// * Per item, a 768-byte record = the six rows of R (six 128-byte lines) and nothing else: all the per-view
+//   elimination reads. V is symmetric and its readers take the lower triangle (n <= m), so the view's six entries
+//   of J^T r, g_v, ride in six slots of V's strictly upper triangle (gvSlot). Rounds 1-3 kept a 1 KiB record
+//   (R, the whole of g, sum r^2: 113 of 128 doubles, 87 of them ever read); the per-view kernels stream the
+//   records of both buffers every LM round, and on large shards that traffic is what they are bound by.
 // * Per workgroup of the kernel that forms them (4 waves = up to 4 items), one partial of what is
 //   only ever needed summed over all views: B, g_c = g[0:L], sum r^2.
 constexpr int kGRows = 0;         // R[m][c] at m * 16 + c
-constexpr int kGg = 96;           // g[c]
-constexpr int kGSse = 112;        // sum r^2
-constexpr int kGHead = 113;
-constexpr int kGStride = 128;     // doubles per item record (1 KiB)
+constexpr int kGStride = 96;      // doubles per item record (768 B)
+// record slot of g_v[j] = (J^T r)[L + j]: V(0, 1..5) for j = 0..4, V(1, 2) for j = 5
+__host__ __device__ __forceinline__ constexpr int gvSlot(int L, int j) { return j < 5 ? L + 1 + j : 16 + L + 2; }
+// the j a record slot carries g_v[j] for, or -1
+__host__ __device__ __forceinline__ constexpr int gvOfSlot(int L, int slot) {
+    const int m = slot >> 4, n = (slot & 15) - L;
+    return (m == 0 && n >= 1 && n <= 5) ? n - 1 : ((m == 1 && n == 2) ? 5 : -1);
+}
 constexpr int kPartStride = 112;  // doubles per workgroup partial: B (L*L), g_c (L), sum r^2
 constexpr int kMaxL = 10;
 
@@ -68,8 +76,7 @@ inline void buildEmitTable(int C, uint32_t* tab /* kEmitTabSize */) {
     for (int i = 0; i < kEmitTabSize; ++i) tab[i] = both(Z);
     for (int m = 0; m < 6; ++m)
         for (int c = 0; c < 16; ++c) tab[kGRows + m * 16 + c] = entry(L + m, c);
-    for (int c = 0; c < C; ++c) tab[kGg + c] = gentry(c);
-    tab[kGSse] = sse;
+    for (int j = 0; j < 6; ++j) tab[gvSlot(L, j)] = gentry(L + j);
     uint32_t* part = tab + kGStride;
     for (int r = 0; r < L; ++r)
         for (int c = 0; c < L; ++c) part[r * L + c] = entry(r, c);
@@ -349,12 +356,10 @@ __global__ __launch_bounds__(256) void gram_kernel(const typename Pair<T>::type*
     if (sub == 0 && valid) {
         double* G = Gbase + (int64_t)item * kGStride;
         for (int i = lane; i < kGStride; i += 64) {
-            const int idx = i < 96 ? (L + i / 16) * 16 + i % 16 : (i < 112 ? 256 + (i - 96) : 272);
-            double t = 0.0;
-            if (i < kGHead) {
-                t = stile[wave][idx];
-                for (int w = 1; w < wpi; ++w) t += stile[wave + w][idx];
-            }
+            const int j = gvOfSlot(L, i);
+            const int idx = j >= 0 ? 256 + L + j : (L + i / 16) * 16 + i % 16;
+            double t = stile[wave][idx];
+            for (int w = 1; w < wpi; ++w) t += stile[wave + w][idx];
             G[i] = t;
         }
     }
@@ -440,7 +445,8 @@ __global__ __launch_bounds__(64 * WAVES, (sizeof(T) == 4 ? ((MULTI && ModelTrait
     double* Gbase = sel ? ((st->cur ^ 1) ? G1 : G0) : G0;
     // One wave per item (tile forms): the item's record goes to HBM straight from the accumulators (lane (k, c) holds
     // rows k + 4 reg -- 4 k + reg behind the fp32 MFMA -- of column c; 16 lanes store 128 contiguous bytes): rows
-    // L..L+5 of J^T J, then J^T r and sum r^2 from the residual's row. No table, no LDS, nothing to wait for.
+    // L..L+5 of J^T J but for the six slots that carry g_v, which the residual's row fills. No table, no LDS,
+    // nothing to wait for.
     auto emitDirect = [&](int it) {
         constexpr int L = C - 6, RESROW = RCOL ? 15 : 4;
         double* G = Gbase + (int64_t)it * kGStride;
@@ -456,14 +462,10 @@ __global__ __launch_bounds__(64 * WAVES, (sizeof(T) == 4 ? ((MULTI && ModelTrait
                 val = c == 3 ? acc[reg] : (c == 4 ? fromLeft : val);
             }
             if (row >= L && row < L + 6) {
-                G[kGRows + (row - L) * 16 + c] = (RCOL && c == 15) ? 0.0 : val;
+                const int slot = kGRows + (row - L) * 16 + c;
+                if (gvOfSlot(L, slot) < 0) G[slot] = (RCOL && c == 15) ? 0.0 : val;
             } else if (row == RESROW) {
-                if (RCOL) {
-                    G[c == 15 ? kGSse : kGg + c] = val;
-                } else {
-                    G[kGg + c] = val;
-                    if (c == 4) G[kGSse] = acc[reg] + acc2[reg];
-                }
+                if (c >= L && c < L + 6) G[gvSlot(L, c - L)] = val;
             }
         }
     };
@@ -718,8 +720,8 @@ __global__ __launch_bounds__(64 * WAVES, (sizeof(T) == 4 ? ((MULTI && ModelTrait
     }
     if ((!G44 && wpi == 1) || sub != 0 || !valid) return;       // the item's first wave assembles the record from the parked tiles
     double* G = Gbase + (int64_t)item * kGStride;
-    {
-        const int i0 = 2 * lane;                                // kGStride = 128: one pass
+    if (lane < kGStride / 2) {
+        const int i0 = 2 * lane;                                // kGStride = 96: lanes 0..47, one pass
         const uint2 t = *reinterpret_cast<const uint2*>(emit_tab + i0);
         double2 o;
         o.x = TU[t.x & 0xffff] + TV[t.x >> 16];
@@ -791,9 +793,7 @@ inline bool buildStreamOps(int C, int32_t* ops /* 64 * kStreamOps */) {
             if (ops[lane * kStreamOps + j] == kStreamNoOp) { ops[lane * kStreamOps + j] = slot * 8; return; }
         ok = false;
     };
-    for (int slot = 0; slot < kGHead; ++slot) {
-        const bool wanted = slot < kGg || (slot >= kGg + L && slot < kGg + L + 6);
-        if (!wanted) continue;
+    for (int slot = 0; slot < kGStride; ++slot) {
         const int iu = (int)(tab[slot] & 0xffff), iv = (int)(tab[slot] >> 16);
         if (iu == kEmitZero && iv == kEmitZero) continue;
         if (iu != kEmitZero && iv != kEmitZero) {
@@ -813,8 +813,11 @@ inline bool buildStreamOps(int C, int32_t* ops /* 64 * kStreamOps */) {
     return ok;
 }
 
+#ifndef CALIB_STREAM_MIN_BLOCKS
+#define CALIB_STREAM_MIN_BLOCKS 4       // workgroups per CU the register allocation leaves room for (A/B builds: 3, 5)
+#endif
 template <int MODEL>
-__global__ __launch_bounds__(256, 4) void fused_stream_kernel(const double* __restrict__ P0, const double* __restrict__ P1,
+__global__ __launch_bounds__(256, CALIB_STREAM_MIN_BLOCKS) void fused_stream_kernel(const double* __restrict__ P0, const double* __restrict__ P1,
                                                               const double2* __restrict__ uv, const double2* __restrict__ XY,
                                                               const double* __restrict__ Z, const double* __restrict__ VC,
                                                               int n, int nv, int share,
@@ -1222,29 +1225,27 @@ __device__ __forceinline__ double row_bcast(double v) {
 // WIDE form in two steps, so that a kernel can have the next view's rows in flight while it factors this one:
 // the raw column-c elements of the six rows and of the gradient row (summed over the view's items) ...
 __device__ __forceinline__ void request_head_rows(const double* __restrict__ G, int item0, int nitems, int extra, int c,
-                                                  double (&r)[7]) {
+                                                  double (&r)[6]) {
     const double* g = G + (int64_t)item0 * kGStride;
 #pragma unroll
     for (int m = 0; m < 6; ++m) r[m] = g[kGRows + m * 16 + c];
-    r[6] = g[kGg + c];
     for (int it = 1; it < nitems; ++it) {                     // > 1 item only for views above kGramChunk points
         g += kGStride;
 #pragma unroll
         for (int m = 0; m < 6; ++m) r[m] += g[kGRows + m * 16 + c];
-        r[6] += g[kGg + c];
     }
     if (extra >= 0) {                                         // stream form: the part of the view a second wave summed
         g = G + (int64_t)extra * kGStride;
 #pragma unroll
         for (int m = 0; m < 6; ++m) r[m] += g[kGRows + m * 16 + c];
-        r[6] += g[kGg + c];
     }
 }
 // ... and their expansion into V and b by broadcasts inside the 16-lane group
 template <int L>
-__device__ __forceinline__ void expand_head_rows(const double (&r)[7], int c, double (&V)[21], double (&b)[6]) {
-    const double gg[6] = {row_bcast<L>(r[6]), row_bcast<L + 1>(r[6]), row_bcast<L + 2>(r[6]),
-                          row_bcast<L + 3>(r[6]), row_bcast<L + 4>(r[6]), row_bcast<L + 5>(r[6])};
+__device__ __forceinline__ void expand_head_rows(const double (&r)[6], int c, double (&V)[21], double (&b)[6]) {
+    // g_v rides in V's upper triangle (gvSlot): V(0, 1..5) and V(1, 2)
+    const double gg[6] = {row_bcast<L + 1>(r[0]), row_bcast<L + 2>(r[0]), row_bcast<L + 3>(r[0]),
+                          row_bcast<L + 4>(r[0]), row_bcast<L + 5>(r[0]), row_bcast<L + 2>(r[1])};
 #pragma unroll
     for (int m = 0; m < 6; ++m) {
         V[tri(m, 0)] = row_bcast<L>(r[m]);
@@ -1262,17 +1263,19 @@ __device__ __forceinline__ void load_view_head(const double* __restrict__ G, int
                                                double (&V)[21], double (&b)[6]) {
     const double* g = G + (int64_t)item0 * kGStride;
     if constexpr (WIDE) {
-        double r[7];
+        double r[6];
         request_head_rows(G, item0, nitems, extra, c, r);
         expand_head_rows<L>(r, c, V, b);
     } else {
-        const int boff = c < L ? kGRows + c : kGg + L;        // + m * 16 (view rows) resp. + m (gradient)
+        // this lane's right-hand side: row c of E at m * 16 + c, or g_v at gvSlot(L, m) = L + 1 + m (m < 5), 16 + L + 2
+        const int boff = c < L ? kGRows + c : gvSlot(L, 0);
         const int bstep = c < L ? 16 : 1;
+        const int b5 = c < L ? kGRows + 5 * 16 + c : gvSlot(L, 5);
 #pragma unroll
         for (int m = 0; m < 6; ++m) {
 #pragma unroll
             for (int n = 0; n <= m; ++n) V[tri(m, n)] = g[kGRows + m * 16 + L + n];
-            b[m] = g[boff + m * bstep];
+            b[m] = g[m < 5 ? boff + m * bstep : b5];
         }
         for (int it = 1; it < nitems; ++it) {                 // > 1 item only for views above kGramChunk points
             g += kGStride;
@@ -1280,7 +1283,7 @@ __device__ __forceinline__ void load_view_head(const double* __restrict__ G, int
             for (int m = 0; m < 6; ++m) {
 #pragma unroll
                 for (int n = 0; n <= m; ++n) V[tri(m, n)] += g[kGRows + m * 16 + L + n];
-                b[m] += g[boff + m * bstep];
+                b[m] += g[m < 5 ? boff + m * bstep : b5];
             }
         }
         if (extra >= 0) {                                     // stream form: the part of the view a second wave summed
@@ -1289,7 +1292,7 @@ __device__ __forceinline__ void load_view_head(const double* __restrict__ G, int
             for (int m = 0; m < 6; ++m) {
 #pragma unroll
                 for (int n = 0; n <= m; ++n) V[tri(m, n)] += g[kGRows + m * 16 + L + n];
-                b[m] += g[boff + m * bstep];
+                b[m] += g[m < 5 ? boff + m * bstep : b5];
             }
         }
     }
@@ -1416,7 +1419,7 @@ __global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __r
         for (int m = 0; m < 6; ++m) z[m] = 0.0;
         const bool live = v0 + grp < nv;                      // whole 16-lane group together
         const bool more = v0 + stride + grp < nv;
-        double rn[7];
+        double rn[6];
         if (WIDE && more) {                                   // the next trip's seven rows: in flight during this elimination
             const int v = v0 + stride + grp, i0 = view_item0 ? view_item0[v] : v;
             request_head_rows(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, (STREAM ? stream_extra_item(sm, v) : -1), c, rn);
@@ -1974,7 +1977,7 @@ __global__ __launch_bounds__(kSchurThreads, 4) void update_backsub_kernel(
     // grid-stride over views: the decision / solve above is paid once per workgroup, not per view
     const int stride = gridDim.x * (kSchurThreads / 16);
     int v = blockIdx.x * (kSchurThreads / 16) + (tid >> 4);
-    double rn[7];
+    double rn[6];
     if (WIDE && v < nv) {
         const int i0 = view_item0 ? view_item0[v] : v;
         request_head_rows(G, i0, view_item0 ? view_item0[v + 1] - i0 : 1, (STREAM ? stream_extra_item(sm, v) : -1), c, rn);

@@ -186,7 +186,7 @@ def test_record_emission_tables_cover_every_read_entry_once(tmp_path):
                     os.path.join(ROOT, "tests", "host_cpp", "stream_ops_check.cpp")], check=True, capture_output=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "C=15: 96 record entries" in out.stdout and "C=16: 102 record entries" in out.stdout
+    assert "C=15: 90 record entries" in out.stdout and "C=16: 96 record entries" in out.stdout   # six 16-wide rows; fisheye has no column 15
     # ... and stream_extra_item (which overflow record holds the rest of a view cut by a wave start) agrees with a
     # direct simulation of the cuts on a few thousand (groups per view, views, waves) combinations
     assert "wave cuts:" in out.stdout and out.stdout.rstrip().endswith("ok")
