@@ -67,6 +67,14 @@ def countersMatchBuild():
         return None
 
 
+def counterEntry(workload):
+    """the whole profiles/pmc_fused.json entry of a workload ({} when there is none)"""
+    try:
+        return json.load(open(PMC_FILE)).get(workload) or {}
+    except Exception:
+        return {}
+
+
 def measuredCounters(workload, model):
     """-> (valu fp64 flops per 64-lane batch or None, fused kernel HBM bytes per launch or None,
     jacobian kernel HBM bytes per launch or None, source string)"""
@@ -149,6 +157,72 @@ def cpuBaseline(shard, cfgName, seconds=20.0, denseOnly=False):
     }
 
 
+def apiEndToEnd(cca, synthetic, shard, cfg, workload, local, noise):
+    """The drop-in API above the C-ABI, end to end and split by stage (not part of `value`; rank 0, N = 1):
+    * `Calibrator.refineCalibrationParameters(A, W, k, allDetections, 50)` -- the reference's own call
+      (src/calibrate.py:117-118) -- from a LIST of per-view (sensor, model) arrays of this workload: compose P on the
+      device, pack the list (src/calibrate.py:277-282's vstack, once), upload, LM with the reference's stop rule,
+      decompose; point-residuals/s = points x iterations executed / wall time of the whole call;
+    * `Calibrator.refinePacked` on the c5 per-GPU shard (125 000 views x 88 points, already stacked arrays): compare /
+      upload / LM."""
+    out = {}
+    Model = cca.FisheyeModel if cfg["model"] == "fisheye" else cca.RadialTangentialModel
+    cal = cca.Calibrator(Model(), dtype=cfg["dtype"], device=local)
+    try:
+        offs, s, m = shard["viewOffsets"], shard["sensorPoints"], shard["modelPoints"]
+        dets = [(s[a:b], m[a:b]) for a, b in zip(offs[:-1], offs[1:])]
+        A0, W0, k0 = cal._decomposeParameterVector(shard["P0"])
+        cal.refineCalibrationParameters(A0, W0[:8], k0, dets[:8], 2)          # engine creation, code objects
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            sse, A, W, k = cal.refineCalibrationParameters(A0, W0, k0, dets, 50)
+            wall = time.perf_counter() - t0
+            if best is None or wall < best[0]:
+                best = (wall, dict(cal.lastSeconds), sse)
+        wall, sec, sse = best
+        iters = int(sec.pop("iters"))
+        MN = int(offs[-1])
+        out["refineCalibrationParameters"] = {
+            "workload": f"{workload}: list of {len(dets)} views x {shard['pointsPerView']} pts, maxIters 50, the reference's stop rule",
+            "wall_ms": wall * 1e3, "iterations_executed": iters, "final_sse": sse,
+            "value": MN * iters / wall, "unit": "point-residuals/s",
+            "stage_ms": {k_: v * 1e3 for k_, v in sec.items()},
+            "host_overhead_ms": (wall - sec.get("lm", 0.0) - sec.get("upload", 0.0)) * 1e3,
+            "best_of": 3}
+    finally:
+        cal.close()
+    try:
+        c5 = dict(synthetic.CONFIGS["c5"])
+        sh = synthetic.makeShard(c5, viewStart=0, numViews=c5["views"] // 8, noiseSigma=noise, device=local)
+        cal5 = cca.Calibrator(cca.RadialTangentialModel(), dtype="f64", device=local)
+        try:
+            args5 = (sh["P0"], sh["viewOffsets"], sh["sensorPoints"], sh["modelPoints"], 30)
+            cal5.refinePacked(*args5)                                           # first call: engine + pinned staging
+            t0 = time.perf_counter()
+            _, _, it5, _ = cal5.refinePacked(*args5)
+            wall = time.perf_counter() - t0
+            sec = dict(cal5.lastSeconds)
+            sec.pop("iters", None)
+            t0 = time.perf_counter()
+            _, _, it5b, _ = cal5.refinePacked(*args5, sameProblem=True)
+            wallSame = time.perf_counter() - t0
+            MN5 = int(sh["viewOffsets"][-1])
+            out["refinePacked_c5_shard"] = {
+                "workload": f"c5 per-GPU shard: {c5['views'] // 8} views x {sh['pointsPerView']} pts, stacked arrays, maxIters 30",
+                "wall_ms": wall * 1e3, "iterations_executed": int(it5), "value": MN5 * int(it5) / wall,
+                "unit": "point-residuals/s", "stage_ms": {k_: v * 1e3 for k_, v in sec.items()},
+                "host_overhead_ms": (wall - sec.get("lm", 0.0) - sec.get("upload", 0.0)) * 1e3,
+                "upload_GBps": MN5 * 40 / sec["upload"] / 1e9 if sec.get("upload") else None,
+                "same_problem_call": {"wall_ms": wallSame * 1e3, "value": MN5 * int(it5b) / wallSame,
+                                      "what": "sameProblem=True: the caller vouches for unchanged arrays, no compare, no upload"}}
+        finally:
+            cal5.close()
+    except Exception as e:          # the c5 shard needs ~1.5 GB of host memory and ~10 s of pose sampling
+        out["refinePacked_c5_shard"] = {"error": str(e)}
+    return out
+
+
 def strongShardRange(totalViews, world, rank):
     """views [start, end) of `rank` when `totalViews` views of one global problem are split over `world` ranks"""
     from camera_calibration_amd import distributed
@@ -173,6 +247,7 @@ def main():
     ap.add_argument("--views", type=int, default=None, help="views per GPU (default: the config's)")
     ap.add_argument("--noise", type=float, default=0.1, help="sensor noise sigma in px")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api", action="store_true", help="skip the api_end_to_end block (Calibrator-level calls, N = 1 only)")
     ap.add_argument("--scaling", choices=["both", "weak", "strong"], default="both",
                     help="N > 1: 'weak' = every rank holds the config's per-GPU views (this is `value`); 'strong' = the "
                          "config's global problem split N ways (block `strong`); 'both' (default) measures the two")
@@ -526,6 +601,13 @@ def main():
             tfl = lambda fl: fl / sec / 1e12
             mfmaName = "v_mfma_f32_16x16x4_f32" if not f64 else ("v_mfma_f64_4x4x4_4b_f64" if blockForm else "v_mfma_f64_16x16x4_f64")
             kname = "fused_stream_kernel" if stream else "fused_kernel"
+            ce = counterEntry(args.workload)
+            share, waves = eng.fusedForm()
+            # the counters describe a launch of a given shape: same build (digest of the device sources) AND same launch
+            # width (share / waves depend on the CU count and on CALIB_STREAM_WAVES)
+            sameShape = (ce.get("fused_form") or {}) == {"share": share, "waves": waves} if ce.get("fused_form") else None
+            simdCycles = 4 * 256 * sec * 2.4e9                   # 256 CUs x 4 SIMDs at the 2.4 GHz the chip reports under load
+            mfmaBusy = ce.get("mfma_busy_cycles_per_launch")
             mainRoof = {"kernel": kname + " (jacobian blocks + " + mfmaName + " J^T J, J on-chip)",
                         "bound": "mfma", "achieved": tfl(contractFlops), "peak": peak, "unit": "TFLOP/s",
                         "frac": tfl(contractFlops) / peak,
@@ -535,6 +617,12 @@ def main():
                         "hbm_frac": 5 * w * fusedPts / sec / 1e9 / HBM_PEAK_GBS,
                         "traffic": fusedTraffic, "traffic_source": pmcSource if fusedTraffic else None,
                         "counters_are_of_this_build": countersMatchBuild(),
+                        "counters_are_of_this_launch_shape": sameShape,
+                        "mfma_busy_frac_counters": (mfmaBusy / simdCycles) if mfmaBusy else None,
+                        "mfma_busy_frac_counters_is": "SQ_VALU_MFMA_BUSY_CYCLES per launch (PMC pass, profiles/pmc_fused.json) / (1024 SIMDs x this "
+                                                      "run's launch duration x 2.4 GHz): the matrix pipe's own busy time, independent of any flop count",
+                        "lds_bank_conflict_frac_counters": ce.get("lds_bank_conflict_frac"),
+                        "wait_inst_any_frac_counters": ce.get("wait_inst_any_frac"),
                         "mfma_flops_per_launch": contractFlops, "mfma_flops_executed_per_launch": mfmaExecuted,
                         "valu_fp64_flops_per_launch_live_points": valuUseful,
                         "valu_flops_source": pmcSource if valuPerBatch else "none: profiles/pmc_fused.json has no entry",
@@ -576,7 +664,8 @@ def main():
                        "ranks_seen": ranksSeen,
                        "exchange_selftest": None if main is None else ("torch.distributed.all_reduce needs none" if main.name == "torch"
                                                                         else "exact sums of rank-dependent values over all ranks, against a deadline, passed on every rank"),
-                       "lm_mode": args.lm_mode},
+                       "lm_mode": args.lm_mode,
+                       "fused_form": dict(zip(("share", "waves"), eng.fusedForm()))},
             "exchange": None if dist is None else {"ms_per_step": exchange, "what": "the same K steps of the weak block with every "
                                                    "carrier of the per-round sum that passed its self-test on every rank "
                                                    "(the peer exchange only with --allreduce all | peer)",
@@ -591,6 +680,9 @@ def main():
                               "mfma_tflops": gramFlops / (gramAvgMs * 1e-3) / 1e12 if gramN else None,
                               "mfma_peak_tflops": FP64_MATRIX_PEAK_TFLOPS,
                               "mfma_util": gramFlops / (gramAvgMs * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TFLOPS if gramN else None,
+                              "superseded_by": "`roofline` (the fused kernel): J never reaches HBM there and the same J^T J runs at "
+                                               "`roofline.frac` of the matrix peak; this kernel re-reads a materialised J and is bound by "
+                                               "the memory system (4 flop/B), which is what its low MFMA utilisation says",
                               "points_per_launch": gramPts, "launches_per_step": gramN / gramSteps,
                               "avg_launch_ms": gramAvgMs, "launches_timed": gramN},
             "valid": bool(iters == total),
@@ -609,6 +701,11 @@ def main():
             # (x10 each): the loop then ends early and later rounds are no-ops -- such a run is not a measurement
             print(f"bench: only {iters} of {total} LM iterations executed (lambda left the fp64 range); "
                   f"use fewer --steps", file=sys.stderr)
+        if world == 1 and not args.no_api and args.lm_mode == "fused":
+            try:
+                out["api_end_to_end"] = apiEndToEnd(cca, synthetic, shard, cfg, args.workload, local, args.noise)
+            except Exception as e:
+                out["api_end_to_end"] = {"error": str(e)}
         if not args.no_cpu_baseline:
             # N = 1: the dense numpy sample and the C/OpenMP port on all host cores (~17 s). N > 1: rank 0 times the
             # dense sample only (a few seconds, the other ranks wait in the closing barrier) -- the host's cores are

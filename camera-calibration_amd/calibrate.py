@@ -30,6 +30,7 @@ class Calibrator:
         self._device = device
         self._resident = engine.ResidentProblem(distortionModel.modelId, dtype, device)
         self.lastTrace = None        # (iters, 5+L) rows of the last refine (see calib_lm.h)
+        self.lastSeconds = {}        # host time of the last refine call by stage: pack / compose / compare / upload / lm / decompose
 
     def close(self):
         """release the resident engine (also happens when the Calibrator is collected)"""
@@ -85,22 +86,32 @@ class Calibrator:
                             "evaluates the closed-form projection Jacobian inside its kernels and cannot consult an "
                             "injected Jacobian object; use jacobian.ProjectionJacobian (or leave _jac unset)")
         maxIters = operator.index(maxIters)
+        t0 = time.perf_counter()
         Pt = self._composeParameterVector(Ainitial, Winitial, kInitial)
+        t1 = time.perf_counter()
         offs, sensor, model = engine.packDetections(allDetections)
+        t2 = time.perf_counter()
         sse, P, iters, trace = self.refinePacked(Pt, offs, sensor, model, maxIters, shouldPrint)
+        t3 = time.perf_counter()
         Arefined, Wrefined, kRefined = self._decomposeParameterVector(P)
+        self.lastSeconds.update(compose=t1 - t0, pack=t2 - t1, decompose=time.perf_counter() - t3)
         return sse, Arefined, Wrefined, kRefined
 
-    def refinePacked(self, P0, viewOffsets, sensorPoints, modelPoints, maxIters, shouldPrint=False):
+    def refinePacked(self, P0, viewOffsets, sensorPoints, modelPoints, maxIters, shouldPrint=False, sameProblem=False):
         """Same loop on already-stacked correspondences (CSR over views): the form that scales
-        to millions of views. -> (sse, P (K,), iters, trace)"""
+        to millions of views. -> (sse, P (K,), iters, trace)
+        sameProblem=True: the caller vouches that these are the (unchanged) arrays of the previous call on this
+        Calibrator -- no compare, no upload (engine.ResidentProblem); by default small problems are recognised by
+        content and large ones are uploaded again."""
         if maxIters <= 0:
             raise UnboundLocalError("local variable 'Pt_error' referenced before assignment")
-        eng = self._resident.get(viewOffsets, sensorPoints, modelPoints)
+        eng = self._resident.get(viewOffsets, sensorPoints, modelPoints, sameProblem=sameProblem)
+        t0 = time.perf_counter()
         if not shouldPrint:
             out = eng.refine(P0, maxIters, self._λinitial, self._λmin, self._λmax, self._Pt_error_min)
         else:
             out = self._refineVerbose(eng, P0, maxIters)
+        self.lastSeconds = dict(self._resident.lastSeconds, lm=time.perf_counter() - t0, iters=int(out[2]))
         self.lastTrace = out[3]
         return out
 

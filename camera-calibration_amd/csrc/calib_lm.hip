@@ -158,12 +158,6 @@ struct calib_handle_s {
     bool exchange_round = false;          // the round being enqueued belongs to a sharded run
     int* host_done = nullptr;             // pinned, device-visible: 1 = the update kernel says the LM loop is over, 2 = a peer exchange gave up
     int* host_done_dev = nullptr;         // the same word as the device sees it
-    // CALIB_SCHUR_SPLIT=1: variant B of the per-view elimination on a second stream, beside the fused kernel
-    int schur_split = 0;
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_state = nullptr, ev_side = nullptr;     // the round's LM state is written / the side launch is done
-    bool ev_state_recorded = false;
-    bool side_pending = false;            // this round's variant B has been enqueued on the side stream
     bool lm_active = false;
     int lm_max_iters = 0;
     int rounds_enqueued = 0;
@@ -464,11 +458,11 @@ bool wide_heads(const calib_handle_s* h) {
     return h->head_loads == 2 || (h->head_loads == 0 && (h->nv > kWideHeadViews || stream_rounds(h)));
 }
 
-int launch_schur(calib_handle_s* h, const LMState* st, hipStream_t stream, int only) {
-    dim3 grid(h->schur_blocks, only == 1 ? 2 : 3);
+int launch_schur(calib_handle_s* h, const LMState* st) {
+    dim3 grid(h->schur_blocks, 3);
     auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, grid, dim3(kSchurBlock), 0, stream, h->G[0].p, h->G[1].p, st, view_items(h), h->nv,
-                           stream_map(h), h->bpart.p, h->n_bpart, h->part.p, only);
+        hipLaunchKernelGGL(kernel, grid, dim3(kSchurBlock), 0, h->stream, h->G[0].p, h->G[1].p, st, view_items(h), h->nv,
+                           stream_map(h), h->bpart.p, h->n_bpart, h->part.p);
     };
     const bool wide = wide_heads(h), strm = stream_rounds(h);
     auto pick = [&](auto Lc) {
@@ -481,31 +475,11 @@ int launch_schur(calib_handle_s* h, const LMState* st, hipStream_t stream, int o
     return CALIB_OK;
 }
 
-// variant B beside the pass over the points (CALIB_SCHUR_SPLIT): enqueued BEFORE the fused kernel, on the side stream,
-// behind the event that says this round's LM state has been written
-int launch_schur_side(calib_handle_s* h, const LMState* st) {
-    if (!h->schur_split || h->nv == 0) return CALIB_OK;
-    if (!h->side_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&h->ev_state, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&h->ev_side, hipEventDisableTiming));
-    }
-    if (h->ev_state_recorded) HIP_TRY(hipStreamWaitEvent(h->side_stream, h->ev_state, 0));
-    const int rc = launch_schur(h, st, h->side_stream, 1);
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(h->ev_side, h->side_stream));
-    h->side_pending = true;
-    return CALIB_OK;
-}
-
 int launch_schur_reduce(calib_handle_s* h, const LMState* st, double* red) {
     const int VA = variantSize(h->L);
     if (h->nv > 0) {
-        const bool split = h->side_pending;
-        h->side_pending = false;
-        const int rc = launch_schur(h, st, h->stream, split ? 0 : -1);
+        const int rc = launch_schur(h, st);
         if (rc) return rc;
-        if (split) HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_side, 0));
     }
     hipLaunchKernelGGL(reduce_kernel, dim3(2 * VA), dim3(64), 0, h->stream, h->part.p,
                        h->nv > 0 ? h->schur_blocks : 0, VA, st, red,
@@ -637,7 +611,6 @@ int calib_create(int model, int dtype, int device_id, calib_handle_t* out_handle
     if (const char* e = std::getenv("CALIB_HEAD_LOADS")) h->head_loads = std::strcmp(e, "narrow") == 0 ? 1 : (std::strcmp(e, "wide") == 0 ? 2 : 0);
     if (const char* e = std::getenv("CALIB_ITEMS_PER_WAVE")) h->items_per_wave = std::max(0, std::min(16, std::atoi(e)));
     if (const char* e = std::getenv("CALIB_GRAM_FORM")) h->gram_form = std::strcmp(e, "tile") == 0 ? 1 : (std::strcmp(e, "block") == 0 ? 2 : 0);
-    if (const char* e = std::getenv("CALIB_SCHUR_SPLIT")) h->schur_split = std::atoi(e) > 0 ? 1 : 0;
     if (const char* e = std::getenv("CALIB_FUSED_STREAM")) h->stream_mode = std::atoi(e) > 0 ? 1 : (std::atoi(e) == 0 ? 0 : -1);
     if (const char* e = std::getenv("CALIB_STREAM_WAVES")) h->stream_waves_env = std::max(0, std::atoi(e));
     {
@@ -690,9 +663,6 @@ int calib_destroy(calib_handle_t h) {
         }
     if (h->stage_pinned) (void)hipHostFree(h->stage_pinned);
     if (h->host_done) (void)hipHostFree(h->host_done);
-    if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
-    if (h->ev_state) (void)hipEventDestroy(h->ev_state);
-    if (h->ev_side) (void)hipEventDestroy(h->ev_side);
     h->uv.release(); h->XY.release(); h->Z.release(); h->VC.release(); h->J.release();
     h->r.release(); h->y.release(); h->pt_view.release(); h->view_ext.release();
     h->item_n.release(); h->view_item0.release(); h->item_view.release(); h->item_pt0.release(); h->sse_part.release();
@@ -1075,7 +1045,6 @@ int calib_lm_begin(calib_handle_t h, const double* P0, int max_iters, double lam
     h->lm_active = true;
     h->lm_max_iters = max_iters;
     h->rounds_enqueued = 0;
-    h->ev_state_recorded = false;         // the stream was drained above: round 0's state is in place
     return CALIB_OK;
 }
 
@@ -1089,8 +1058,6 @@ int calib_lm_local(calib_handle_t h) {
         if (rc) return rc;
     }
     if (h->lm_mode == CALIB_LM_FUSED) {
-        rc = launch_schur_side(h, st);
-        if (rc) return rc;
         rc = launch_fused(h, st, 1);
         if (rc) return rc;
         return launch_schur_reduce(h, st, h->red);
@@ -1110,10 +1077,6 @@ int calib_lm_update(calib_handle_t h) {
     if (!h->lm_active) return fail(CALIB_E_STATE, "calib_lm_begin has not been called");
     const int rc = launch_update_backsub(h);
     h->rounds_enqueued += 1;
-    if (rc == CALIB_OK && h->schur_split && h->side_stream) {
-        HIP_TRY(hipEventRecord(h->ev_state, h->stream));
-        h->ev_state_recorded = true;
-    }
     return rc;
 }
 

@@ -774,7 +774,6 @@ constexpr int kStreamNoOp = 0x7ffffff0;
 inline bool buildStreamOps(int C, int32_t* ops /* 64 * kStreamOps */) {
     uint32_t tab[kEmitTabSize];
     buildEmitTable(C, tab);
-    const int L = C - 6;
     for (int i = 0; i < 64 * kStreamOps; ++i) ops[i] = kStreamNoOp;
     struct Src { int lane, acc; };          // acc: 0 d0u, 1 d0v, 2 d1u, 3 d1v, 4 d2
     const auto laneOf = [](int k, int b, int x) { return k * 16 + b * 4 + x; };
@@ -953,10 +952,7 @@ __global__ __launch_bounds__(256, CALIB_STREAM_MIN_BLOCKS) void fused_stream_ker
             d1v = __builtin_amdgcn_mfma_f64_4x4x4f64(ja.y, jb.y, d1v, 0, 0, 0);
             d2u = __builtin_amdgcn_mfma_f64_4x4x4f64(ha, hc, d2u, 0, 0, 0);
         };
-        // Stage A of the NEXT batch's per-point model (projection + distortion: the long dependent chains) can be run in
-        // slices between the groups of this batch's second pass: pst then holds it when the next batch begins
         PointState<MODEL, T> pst;
-        bool havePst = false;
         SSTAMP(0);
         for (int q0 = p0; q0 < p1; q0 += 64) {
             const int qe = q0 + 64 < p1 ? q0 + 64 : p1;
@@ -986,7 +982,7 @@ __global__ __launch_bounds__(256, CALIB_STREAM_MIN_BLOCKS) void fused_stream_ker
             T u, v;
             T2 Jc[C];
             if (!strad) {
-                if (!havePst) jacobian_stage_a<MODEL, T>(sp, vcs, xy.x, xy.y, z, pst);
+                jacobian_stage_a<MODEL, T>(sp, vcs, xy.x, xy.y, z, pst);
                 jacobian_stage_b<MODEL, T>(sp, vcs, pst, u, v, Jc);
             } else {
                 // two views: every lane reads the constants of its own from the staged pair
@@ -1015,7 +1011,6 @@ __global__ __launch_bounds__(256, CALIB_STREAM_MIN_BLOCKS) void fused_stream_ker
             // the SGPRs of the view constants are free now: the next one-view batch's arrive during the contraction
             if (more && !strad2) scalarLoad(vfirst2);
             strad = strad2;
-            havePst = false;
             // chunk pairs through v_permlane32_swap: one full-width store per pair and pass (see fused_kernel)
             constexpr int NCH = C - 5 + 1;                      // columns 5..C-1 and the residual
             T2 ch[NCH];
@@ -1054,36 +1049,7 @@ __global__ __launch_bounds__(256, CALIB_STREAM_MIN_BLOCKS) void fused_stream_ker
                 SSTAMP(4);
                 const int ng = (p1 - ps >= ROWS ? ROWS : p1 - ps) >> 2;   // groups of the pass (shares are whole groups)
                 const int jb = (vend - ps) >> 2;                // the group a new view starts with (>= ng: none here)
-                // (measured, round 3: c3 45.3 -> 62.1 us, c5 shard 230 -> 438 us. Stage A's 10 carried values and its
-                // temporaries on top of the accumulators and the operands in flight do not fit the 128 VGPRs of four waves
-                // per SIMD: 27-33 spilled registers, ~20 scratch reloads per batch. Kept behind a macro for the record.)
-#ifdef CALIB_STREAM_INTERLEAVE
-                constexpr bool kInterleave = true;
-#else
-                constexpr bool kInterleave = false;
-#endif
-                if (kInterleave && ng == ROWS / 4 && jb >= ROWS / 4 && half == 1 && more && !strad2) {
-                    // EXPERIMENT (off): a whole second pass inside one view, and a one-view batch next: stage A of the next
-                    // batch's points (their coordinates and their view's constants have arrived) runs in eight slices, one
-                    // behind each group's five MFMAs -- matrix and vector instructions of the SAME wave overlap (ubench10),
-                    // and the dependent chains of stage A (reciprocals, arctangent) fill the matrix instructions' shadow
-                    T2 ja = src[c], jbb = src[c1];
-                    double ha = h0[0], hc = h2[0];
-                    jacobian_stage_a<MODEL, T>(sp, vcs, xy_n.x, xy_n.y, z_n, pst, [&](int s) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        contract(ja, jbb, ha, hc);
-                        if (s + 1 < ROWS / 4) {
-                            ja = src[66 * (s + 1) + c]; jbb = src[66 * (s + 1) + c1];
-                            ha = h0[2 * 66 * (s + 1)]; hc = h2[2 * 66 * (s + 1)];
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    });
-                    havePst = true;
-#ifdef CALIB_STREAM_STAMPS
-                    asm volatile("" :: "v"(d0u), "v"(d0v), "v"(d1u), "v"(d1v), "v"(d2u));
-#endif
-                    SSTAMP(5);
-                } else if (ng == ROWS / 4 && jb >= ROWS / 4) {
+                if (ng == ROWS / 4 && jb >= ROWS / 4) {
                     // a whole pass inside one view: every address is the wave's constant base plus an immediate
                     // the operands of group s + 1 are requested before group s is contracted
                     T2 ja = src[c], jbb = src[c1];
@@ -1349,17 +1315,15 @@ __global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __r
                                                             const LMState* __restrict__ st,
                                                             const int* __restrict__ view_item0,
                                                             int nv, StreamMap sm, const double* __restrict__ bpart,
-                                                            int n_bpart, double* __restrict__ part, int only) {
+                                                            int n_bpart, double* __restrict__ part) {
     constexpr int VA = variantSize(L);
     constexpr int kNfail = 2 * L * L + 2 * L, kSse = kNfail + 1;
     __shared__ double sfail[kSchurViewsPerBlock];
     __shared__ double stile[kSchurBlock / 64][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = tid & 15, grp = tid >> 4, k = lane >> 4;
 
-    // only: -1 = everything; 0 = variant A and the sums; 1 = variant B alone (launched beside the pass over the points:
-    // the current blocks and the lambda it damps them with are known since the previous round's update)
     if (blockIdx.y == 2) {
-        if (only == 1 || st->done) return;
+        if (st->done) return;
         // thread t of each half-block owns one field of the workgroup partials of B, g_c, sum r^2
         constexpr int NF = L * L + L + 1;
         double* out = part + (int64_t)blockIdx.x * VA;
@@ -1402,7 +1366,6 @@ __global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __r
     const bool boot = st->round == 0;
     const int cand = st->cur ^ 1;
     const int variant = (int)blockIdx.y == cand ? 0 : 1;
-    if (only >= 0 && variant != only) return;
     double* out = part + ((int64_t)variant * gridDim.x + blockIdx.x) * VA;
     if (variant == 1 && boot) {       // no "current" blocks yet
         for (int i = tid; i < VA; i += kSchurBlock) out[i] = 0.0;

@@ -72,19 +72,10 @@ __device__ __forceinline__ double fma_sconst(double a, double b, double sc) {   
     return r;
 }
 
-// Stage hooks: the per-point model can be evaluated in slices with a caller's work between them (fused_stream_kernel
-// contracts one 4-point group of the previous batch per slice: an MFMA followed by independent VALU work of the SAME
-// wave overlaps, tools/ubench/ubench10). NoHook = straight through.
-struct NoHook {
-    __device__ __forceinline__ void operator()(int) const {}
-};
-
 // atan(r) for r >= 0 given ir = 1 / r (any value when r == 0): t = min(r, 1/r) in [0, 1],
 // atan(t) = t P(t^2) with P the degree-19 interpolant of atan(sqrt z) / sqrt z at the Chebyshev nodes of
 // [0, 1] (coefficients computed with mpmath at 60 digits, max relative error 2.5e-16), pi/2 - atan(1/r) above 1.
-// hook(H0) and hook(H0 + 1) are called a third and two thirds of the way through the Horner chain.
-template <int H0, class Hook>
-__device__ __forceinline__ double atan_pos(double r, double ir, Hook&& hook) {
+__device__ __forceinline__ double atan_pos(double r, double ir) {
     const bool big = r > 1.0;
     const double t = big ? ir : r;
     const double z = t * t;
@@ -92,19 +83,12 @@ __device__ __forceinline__ double atan_pos(double r, double ir, Hook&& hook) {
 #pragma unroll
     for (int j = 1; j < 19; ++j) {
         p = fma_sconst(p, z, kAtanPoly[j]);
-        if (j == 6) hook(H0);
-        if (j == 12) hook(H0 + 1);
     }
     p = __builtin_fma(p, z, 1.0);
     const double a = t * p;
     return big ? 1.5707963267948966 - a : a;
 }
-template <int H0, class Hook>
-__device__ __forceinline__ float atan_pos(float r, float, Hook&& hook) {
-    hook(H0);
-    hook(H0 + 1);
-    return atanf(r);
-}
+__device__ __forceinline__ float atan_pos(float r, float) { return atanf(r); }
 
 template <int MODEL, typename T>
 struct Shared {               // the L shared parameters, converted once per thread
@@ -124,18 +108,14 @@ template <int MODEL, typename T> struct DistortCore;
 template <typename T> struct DistortCore<kRadtan, T> { T r2, rad, drad; };
 template <typename T> struct DistortCore<kFisheye, T> { T s, sror, p, t2; };     // p = theta^3 / r (the k1 factor)
 
-// calls hook(2) .. hook(7), once each and in order, between slices of its arithmetic
-template <int MODEL, typename T, class Hook = NoHook>
-__device__ __forceinline__ void distort_core(const T* __restrict__ k, T x, T y, DistortCore<MODEL, T>& c,
-                                             Hook&& hook = Hook()) {
+template <int MODEL, typename T>
+__device__ __forceinline__ void distort_core(const T* __restrict__ k, T x, T y, DistortCore<MODEL, T>& c) {
     const T r2 = x * x + y * y;
     if constexpr (MODEL == kRadtan) {
         const T k1 = k[0], k2 = k[1], k3 = k[4];
         c.r2 = r2;
         c.rad = T(1) + r2 * (k1 + r2 * (k2 + r2 * k3));
-        hook(2);
         c.drad = k1 + r2 * (T(2) * k2 + T(3) * k3 * r2);
-        hook(3); hook(4); hook(5); hook(6); hook(7);
     } else {
         const T k1 = k[0], k2 = k[1], k3 = k[2], k4 = k[3];
         // 1 / r from a clamped r^2: at r = 0 (a point on the optical axis) ir stays finite and r = r2 * ir = 0,
@@ -143,14 +123,11 @@ __device__ __forceinline__ void distort_core(const T* __restrict__ k, T x, T y, 
         const T tiny = sizeof(T) == 8 ? T(1e-300) : T(1e-30);
         const T ir = fast_rsqrt(r2 > tiny ? r2 : tiny);
         const T r = r2 * ir;
-        hook(2);
-        const T th = atan_pos<3>(r, ir, hook);           // hook(3), hook(4)
+        const T th = atan_pos(r, ir);
         const T t2 = th * th;
         const T poly = T(1) + t2 * (k1 + t2 * (k2 + t2 * (k3 + t2 * k4)));
-        hook(5);
         const T gp = (T(1) + t2 * (T(3) * k1 + t2 * (T(5) * k2 + t2 * (T(7) * k3 + T(9) * k4 * t2))))
                      * fast_rcp(T(1) + r2);
-        hook(6);
         // s = theta poly / r, s_r / r = (g' - s) / r^2; analytic limits at r -> 0
         // (the reference evaluates 0/0 = NaN exactly at r = 0, src/distortion.py:215).
         T thr;
@@ -163,7 +140,6 @@ __device__ __forceinline__ void distort_core(const T* __restrict__ k, T x, T y, 
         }
         c.p = thr * t2;
         c.t2 = t2;
-        hook(7);
     }
 }
 
@@ -234,20 +210,17 @@ struct PointState {
     DistortCore<MODEL, T> core;
 };
 
-// calls hook(0) .. hook(7), once each and in order
-template <int MODEL, typename T, class Hook = NoHook>
+template <int MODEL, typename T>
 __device__ __forceinline__ void jacobian_stage_a(const Shared<MODEL, T>& sp, const T* __restrict__ vc, T X, T Y, T Z,
-                                                 PointState<MODEL, T>& st, Hook&& hook = Hook()) {
+                                                 PointState<MODEL, T>& st) {
     st.q0 = vc[0] * X + vc[1] * Y + vc[2] * Z;
     st.q1 = vc[3] * X + vc[4] * Y + vc[5] * Z;
     st.q2 = vc[6] * X + vc[7] * Y + vc[8] * Z;
     const T Xc = st.q0 + vc[9], Yc = st.q1 + vc[10], Zc = st.q2 + vc[11];
-    hook(0);
     st.iz = fast_rcp(Zc);
     st.x = Xc * st.iz;
     st.y = Yc * st.iz;
-    hook(1);
-    distort_core<MODEL, T>(sp.k, st.x, st.y, st.core, hook);
+    distort_core<MODEL, T>(sp.k, st.x, st.y, st.core);
 }
 
 template <int MODEL, typename T>

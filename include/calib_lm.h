@@ -81,7 +81,12 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
  *                        MFMA without writing them to HBM (default; fastest);
  *   CALIB_LM_TWO_KERNEL  the jacobian kernel materialises the compact J in HBM (the layout
  *                        calib_eval returns) and the gram kernel reads it back.
- * Both produce the same blocks (fixed, identical summation order per view item). */
+ * Both produce the same blocks up to summation order. Every sum is fixed-order, so a run is bitwise reproducible for a
+ * given shard, mode and device. Bit-identity ACROSS modes, shard splits and devices holds for the one-view-per-wave
+ * forms only: the stream form of the fused kernel (calib_fused_form) sums a view that a wave start cuts in two parts,
+ * and where the cuts fall depends on the launch width (CU count, CALIB_STREAM_WAVES) -- "same sums, order fixed per
+ * (shard shape, launch width)", 1e-13 relative between forms. CALIB_FUSED_STREAM=0 keeps the one-view-per-wave forms
+ * for callers who need bit-reproducibility across devices. */
 enum { CALIB_LM_FUSED = 0, CALIB_LM_TWO_KERNEL = 1 };
 int calib_set_lm_mode(calib_handle_t h, int mode);
 /* Which form of the fused kernel the loaded problem's rounds run in (decided by calib_set_problem from the shard's

@@ -294,6 +294,31 @@ def test_resident_problem_notices_in_place_changes_of_the_callers_arrays():
     fresh.close()
 
 
+def test_resident_problem_large_problems_are_uploaded_not_compared(monkeypatch):
+    """Above engine.RESIDENT_COMPARE_LIMIT a problem is uploaded again on every call (an upload is cheaper than a
+    host compare and can never be stale), unless the caller vouches for it with sameProblem=True."""
+    from camera_calibration_amd import engine
+    g = loadGolden("g3_unittest15.npz")
+    offs, sensor, model = g["viewOffsets"], g["sensorPoints"].copy(), g["modelPoints"].copy()
+    monkeypatch.setattr(engine, "RESIDENT_COMPARE_LIMIT", 1024)
+    cal = cca.Calibrator(cca.RadialTangentialModel())
+    a = cal.refinePacked(g["P0"], offs, sensor, model, 3)
+    b = cal.refinePacked(g["P0"], offs, sensor, model, 3)
+    assert cal._resident.uploads == 2 and a[0] == b[0] and np.array_equal(a[1], b[1])
+    assert cal._resident._model is None                       # no private copies of a large problem
+    c = cal.refinePacked(g["P0"], offs, sensor, model, 3, sameProblem=True)
+    assert cal._resident.uploads == 2 and c[0] == a[0] and np.array_equal(c[1], a[1])
+    assert cal.lastSeconds["upload"] == 0.0 and cal.lastSeconds["compare"] == 0.0 and cal.lastSeconds["lm"] > 0
+    sensor += 0.25
+    d = cal.refinePacked(g["P0"], offs, sensor, model, 3)     # default: never stale
+    assert cal._resident.uploads == 3 and d[0] != a[0]
+    # sameProblem with another shape is not believed
+    e = cal.refinePacked(np.concatenate((g["P0"][:10], g["P0"][10:10 + 6 * 14])), offs[:15], sensor[:offs[14]], model[:offs[14]], 3,
+                         sameProblem=True)
+    assert cal._resident.uploads == 4 and e[1].shape[0] == 10 + 6 * 14
+    cal.close()
+
+
 def test_injected_jacobian_is_refused_not_ignored():
     """The reference's loop calls self._jac.compute every iteration (src/calibrate.py:144) and its tests inject a
     mock there (tests/test_calibrate.py:85-90). The device loop cannot consult such an object: it says so."""
@@ -630,6 +655,34 @@ def test_reference_unit_test_call_shapes():
     y = cal.projectAllPoints(P, [m for s, m in dets])
     assert y.shape[0] > 0 and y.shape[1] == 2
     assert cca.getSensorPoints(dets).shape == y.shape
+
+
+def test_device_homographies_on_the_references_stored_detections():
+    """dlt_kernel / homography_lm_kernel (calib_estimate_homographies) on the reference's one stored, non-synthetic
+    detection set -- 57 corners of a real image, some missing (tests/test_linearcalibrate.py:72-77,266-386) -- and on its
+    known-answer case (:55-70): golden g10 holds what the reference's estimateHomography and _refineHomographies
+    return. H to 1e-8 relative, its reprojections to 1e-6 px; the known answer to the reference's own 1e-3."""
+    from camera_calibration_amd import engine
+    g = loadGolden("g10_real_detections.npz")
+    offs = np.array([0, g["ex_x"].shape[0], g["ex_x"].shape[0] + g["ka_x"].shape[0]], dtype=np.int64)
+    s = np.vstack((g["ex_x"], g["ka_x"]))
+    m = np.vstack((g["ex_X"], g["ka_X"]))
+    H = engine.estimateHomographies(offs, s, m, refineIters=0)
+    assert H.shape == (2, 3, 3)
+    assert np.abs(H[0] - g["ex_H"]).max() <= 1e-8 * np.abs(g["ex_H"]).max()
+    assert np.abs(H[1] - g["ka_H"]).max() <= 1e-8 * np.abs(g["ka_H"]).max()
+    assert np.allclose(H[1], g["ka_Hexpected"], atol=1e-3)
+    p = np.column_stack((g["ex_X"][:, :2], np.ones(g["ex_X"].shape[0])))
+    mine, theirs = p @ H[0].T, p @ g["ex_H"].T
+    assert np.abs(mine[:, :2] / mine[:, 2:3] - theirs[:, :2] / theirs[:, 2:3]).max() < 1e-6
+    Hr = engine.estimateHomographies(offs, s, m, refineIters=20)
+    assert np.abs(Hr[0] - g["ex_Href"]).max() <= 1e-5 * np.abs(g["ex_Href"]).max()
+    mine, theirs = p @ Hr[0].T, p @ g["ex_Href"].T
+    assert np.abs(mine[:, :2] / mine[:, 2:3] - theirs[:, :2] / theirs[:, 2:3]).max() < 1e-5
+    # the facade's single-view call shape (src/calibrate.py:60-67 takes one H and one (x, X) at a time)
+    cal = cca.Calibrator(cca.RadialTangentialModel())
+    Href1 = cal._refineHomographies([g["ex_H"].copy()], [(g["ex_x"], g["ex_X"])])[0]
+    assert np.abs(Href1 - g["ex_Href"]).max() <= 1e-5 * np.abs(g["ex_Href"]).max()
 
 
 def test_device_initialisation_stages_vs_reference():

@@ -123,6 +123,53 @@ def test_linear_initialisation_vs_reference(tag, name):
     assert abs(Hs[0][2, 2] - 1.0) < 1e-15
 
 
+def test_homography_on_the_references_stored_detections():
+    """The reference's one stored, non-synthetic detection set (tests/test_linearcalibrate.py:72-77 with the 57 corners of
+    :266-386: real-image coordinates, missing corners) and its known-answer case (:55-70, Hexpected to 1e-3), golden g10
+    = what the reference's estimateHomography / _refineHomographies return on them; here the batched host stage."""
+    from camera_calibration_amd import linearcalibrate as lc
+    g = loadGolden("g10_real_detections.npz")
+    dets = [(g["ex_x"], g["ex_X"]), (g["ka_x"], g["ka_X"])]
+    Hex, Hka = lc.estimateHomographies(dets)
+    assert np.abs(Hex - g["ex_H"]).max() <= 1e-8 * np.abs(g["ex_H"]).max()
+    assert np.allclose(Hka, g["ka_Hexpected"], atol=1e-3)                  # the reference's own assertion
+    assert np.abs(Hka - g["ka_H"]).max() <= 1e-8 * np.abs(g["ka_H"]).max()
+    Hr = lc.refineHomographies([Hex, Hka], dets)
+    assert np.abs(Hr[0] - g["ex_Href"]).max() <= 1e-5 * np.abs(g["ex_Href"]).max()
+    for H, Hg, (x, X) in ((Hex, g["ex_H"], dets[0]), (Hr[0], g["ex_Href"], dets[0])):
+        p = np.column_stack((X[:, :2], np.ones(X.shape[0])))
+        mine, theirs = p @ H.T, p @ Hg.T
+        assert np.abs(mine[:, :2] / mine[:, 2:3] - theirs[:, :2] / theirs[:, 2:3]).max() < 1e-6      # px
+
+
+def test_pack_detections_fast_path_and_fallback():
+    """engine.packDetections = getSensorPoints' vstack done once (src/calibrate.py:277-282): float64 (N,2)/(N,3) arrays take
+    one pass and one concatenate; lists / other dtypes are converted view by view; shape errors are ValueErrors that
+    name the view (mathutils.validateShape's exception type, src/mathutils.py:102-105)."""
+    rng = np.random.default_rng(3)
+    ns = [5, 1, 17, 4]
+    dets = [(rng.random((n, 2)), rng.random((n, 3))) for n in ns]
+    offs, s, m = engine.packDetections(dets)
+    assert offs.dtype == np.int64 and list(offs) == [0, 5, 6, 23, 27]
+    assert np.array_equal(s, np.vstack([d[0] for d in dets])) and np.array_equal(m, np.vstack([d[1] for d in dets]))
+    assert s.flags["C_CONTIGUOUS"] and m.flags["C_CONTIGUOUS"] and s.dtype == np.float64
+    assert np.array_equal(cca.getSensorPoints(dets), s)
+    mixed = [(dets[0][0].tolist(), dets[0][1].astype(np.float32)), dets[1], (dets[2][0][::1], dets[2][1]), dets[3]]
+    o2, s2, m2 = engine.packDetections(mixed)
+    assert np.array_equal(o2, offs) and np.array_equal(s2, s) and np.allclose(m2, m, atol=1e-7)
+    views = np.vstack([d[0] for d in dets])                       # slices of one array (what bench.py hands over)
+    o3, s3, _ = engine.packDetections([(views[a:b], dets[i][1]) for i, (a, b) in enumerate(zip(offs[:-1], offs[1:]))])
+    assert np.array_equal(s3, s) and not np.shares_memory(s3, views)
+    with pytest.raises(ValueError, match="view 1"):
+        engine.packDetections([dets[0], (np.zeros((3, 2)), np.zeros((4, 3)))])
+    with pytest.raises(ValueError, match="view 0"):
+        engine.packDetections([(np.zeros((3, 3)), np.zeros((3, 3)))])
+    o0, s0, m0 = engine.packDetections([])
+    assert list(o0) == [0] and s0.shape == (0, 2) and m0.shape == (0, 3)
+    om, mm = engine.packModelPoints([d[1] for d in dets])
+    assert np.array_equal(om, offs) and np.array_equal(mm, m)
+
+
 def test_detections_json_roundtrip(tmp_path):
     # tests/test_dataset.py:70-90: exportDetections / createDetectionsFromPath, same JSON schema
     from camera_calibration_amd import dataset

@@ -8,7 +8,7 @@ for rep in 1 2; do
   for v in product $var; do
     if [ $v = product ]; then unset CALIB_LM_LIBRARY; else export CALIB_LM_LIBRARY=$R/camera-calibration_amd/lib/$var/libcalib_lm.so; fi
     for w in $wls; do
-      python3 $R/bench.py --no-cpu-baseline --workload $w 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', '$w', round(d['ms_per_step'],4), round(d['roofline']['avg_launch_ms']*1e3,2))"
+      python3 $R/bench.py --no-cpu-baseline --no-api --workload $w 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', '$w', round(d['ms_per_step'],4), round(d['roofline']['avg_launch_ms']*1e3,2))"
     done
   done
 done

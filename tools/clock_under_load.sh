@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 w=${1:-c3}; shift
 mkdir -p $R/gpurun_out/clk
-python3 $R/bench.py --no-cpu-baseline --workload $w --min-seconds 6 "$@" > $R/gpurun_out/clk/bench_$w.json 2> $R/gpurun_out/clk/bench_$w.err &
+python3 $R/bench.py --no-cpu-baseline --no-api --workload $w --min-seconds 6 "$@" > $R/gpurun_out/clk/bench_$w.json 2> $R/gpurun_out/clk/bench_$w.err &
 pid=$!
 : > $R/gpurun_out/clk/smi_$w.log
 while kill -0 $pid 2>/dev/null; do

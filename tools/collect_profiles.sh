@@ -10,13 +10,14 @@ done
 for w in c2 c4 c5 c5_full c3_s20 c3 c3_nostream c5_nostream; do cp gpurun_out/prof/bench_$w.json profiles/${rnd}_${w}_bench.json; done
 cp gpurun_out/prof/rehearsal_n2.json profiles/${rnd}_rehearsal_n2_gloo_one_gpu.json
 cp gpurun_out/prof/rehearsal_n4.json profiles/${rnd}_rehearsal_n4_gloo_one_gpu.json
+for n in 2 4; do [ -f gpurun_out/prof/rehearsal_n${n}_direct.json ] && cp gpurun_out/prof/rehearsal_n${n}_direct.json profiles/${rnd}_rehearsal_n${n}_direct.json; done
 cp gpurun_out/prof/ubench.txt profiles/${rnd}_ubench.txt
 cp gpurun_out/prof/stream_stamps.txt profiles/${rnd}_stream_stamps.txt
-# 64-lane batches per fused launch: stream shards sum ceil(share points / 64) over the waves (c3: 4065 x 8 + 1, c5 shard: 4092 x 42 + 11)
-python3 tools/make_pmc_fused.py --round $rnd --workload c3 --tag c3 --batches 32521 --model fisheye > /dev/null
-python3 tools/make_pmc_fused.py --round $rnd --workload c5 --tag c5 --batches 171875 --model radtan > /dev/null
-python3 tools/make_pmc_fused.py --round $rnd --workload c2 --tag c2 --batches 1000 --model _c2 > /dev/null
-python3 tools/make_pmc_fused.py --round $rnd --workload c4 --tag c4 --batches 12500 --model _c4 > /dev/null
+# 64-lane batches per fused launch: derived from the launch shape the profiled build reported (config.fused_form in the bench line)
+python3 tools/make_pmc_fused.py --round $rnd --workload c3 --tag c3 --model fisheye > /dev/null
+python3 tools/make_pmc_fused.py --round $rnd --workload c5 --tag c5 --model radtan > /dev/null
+python3 tools/make_pmc_fused.py --round $rnd --workload c2 --tag c2 --model _c2 > /dev/null
+python3 tools/make_pmc_fused.py --round $rnd --workload c4 --tag c4 --model _c4 > /dev/null
 python3 - <<'PY'
 import json
 p = "profiles/pmc_fused.json"

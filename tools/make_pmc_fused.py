@@ -5,7 +5,10 @@ profiles/<round>_<workload>_pmc.json from the counter passes of tools/pmc_pass.s
     python tools/make_pmc_fused.py --round r02 --workload c3 --tag c3 --batches 40000 --model fisheye
 
 --batches = 64-lane batches one fused launch evaluates (one view item per wave: views x ceil(points per view / 64);
-stream form: the sum over the waves of ceil(points of the wave's share / 64)).
+stream form: the sum over the waves of ceil(points of the wave's share / 64)). Without --batches the count is derived
+from the launch shape the profiled build reported for this shard -- `config.fused_form` {share, waves} and the shard's
+views x points in gpurun_out/prof/bench_<tag>.json -- and share / waves are recorded, so that bench.py can tell when it
+runs with another launch width (another CU count, CALIB_STREAM_WAVES) than the counters were taken at.
 Counters are the mean over the dispatches of a kernel; FETCH_SIZE / WRITE_SIZE come in KiB, and on gfx950
 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read, so it is doubled (MI355X_MICROARCH.md, HBM)."""
 import argparse, csv, glob, json, os, subprocess
@@ -53,10 +56,22 @@ def main():
     ap.add_argument("--round", default="r03")
     ap.add_argument("--workload", required=True)
     ap.add_argument("--tag", required=True)
-    ap.add_argument("--batches", type=int, required=True)
+    ap.add_argument("--batches", type=int, default=0)
     ap.add_argument("--model", required=True)
     a = ap.parse_args()
     k = collect(a.tag)
+    form = None
+    if a.batches <= 0:
+        line = json.loads(open(os.path.join(ROOT, "gpurun_out", "prof", f"bench_{a.tag}.json")).read())
+        cfg = line["config"]
+        form = cfg["fused_form"]
+        views, n = int(cfg["views_per_gpu"]), int(cfg["points_per_view"])
+        if form["share"] > 0:
+            pts, per = views * n, 4 * form["share"]
+            full, rest = divmod(pts, per)
+            a.batches = full * -(-per // 64) + (-(-rest // 64) if rest else 0)
+        else:
+            a.batches = views * -(-n // 64)
     commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
     out = os.path.join(ROOT, "profiles", f"{a.round}_{a.workload}_pmc.json")
     json.dump({"commit": commit, "command": f"tools/pmc_pass.sh {a.tag} (bench.py --steps 10, workload {a.workload})",
@@ -72,7 +87,13 @@ def main():
     d["kernel_sources_sha256_16"] = sourcesDigest()
     d[a.workload] = {"valu_f64_flops_per_batch": f64 or None, "fused_hbm_bytes_per_launch": traffic(fused),
                      "jacobian_hbm_bytes_per_launch": traffic(jac), "source": src,
-                     "valu_instructions_per_batch": (fused.get("SQ_INSTS_VALU", 0) - fused.get("SQ_INSTS_MFMA", 0)) / a.batches}
+                     "valu_instructions_per_batch": (fused.get("SQ_INSTS_VALU", 0) - fused.get("SQ_INSTS_MFMA", 0)) / a.batches,
+                     "batches_per_launch": a.batches, "fused_form": form,
+                     "mfma_busy_cycles_per_launch": fused.get("SQ_VALU_MFMA_BUSY_CYCLES"),
+                     "lds_bank_conflict_frac": (fused.get("SQ_LDS_BANK_CONFLICT", 0) / fused["SQ_LDS_IDX_ACTIVE"])
+                     if fused.get("SQ_LDS_IDX_ACTIVE") else None,
+                     "wait_inst_any_frac": (fused.get("SQ_WAIT_INST_ANY", 0) / fused["SQ_WAVE_CYCLES"])
+                     if fused.get("SQ_WAVE_CYCLES") else None}
     d.setdefault("by_model", {})[a.model] = {"valu_f64_flops_per_batch": f64 or None, "source": src}
     json.dump(d, open(pf, "w"), indent=1, sort_keys=True)
     print(json.dumps(d[a.workload]))

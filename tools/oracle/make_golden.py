@@ -20,6 +20,9 @@ G6  synthetic-generator poses for the bench boards (src/dataset.py:59-95)
 G7  DLT homographies and their LM polish (src/linearcalibrate.py:7-58, src/calibrate.py:60-115)
 G8  HomographyJacobian.compute and the mathutils helpers exp/skew/unskew/stack/unstack/project/projectStandard
 G9  tests/itest_main.py:31-52 noisy radtan calibration: detections (noise model), start point, LM trace, final A, k
+G10 the reference's one stored, non-synthetic detection set (tests/test_linearcalibrate.py:266-386 getExampleData: 57
+    corners of a real image, with missing corners) through estimateHomography and the LM polish, and the known-answer
+    case of tests/test_linearcalibrate.py:55-70 (Hexpected, the reference asserts atol 1e-3)
 """
 import argparse
 import os
@@ -335,6 +338,30 @@ def g8():
     Xc = rng.uniform(-1, 1, (20, 3)) + np.array([0, 0, 2.5])
     out["projectStandard_X"], out["projectStandard_x"] = Xc, mu.projectStandard(Xc)
     save("g8_surface.npz", **out)
+
+
+def g10():
+    """src/linearcalibrate.py:24-58 (estimateHomography) + src/calibrate.py:69-111 (_refineHomography) on the data the
+    reference's own tests hold: getExampleData() (the coordinates are a fixture: stored as arrays) and the 10-point
+    known-answer case. The test module is imported from /root/reference/tests for its two data helpers only."""
+    sys.path.insert(0, "/root/reference/tests")
+    import test_linearcalibrate as tl
+    out = {}
+    x, X = tl.getExampleData()
+    x, X = np.asarray(x, dtype=np.float64), np.asarray(X, dtype=np.float64)
+    H = ref.linearcalibrate.estimateHomography(x, X[:, :2])
+    cal = ref.calibrate.Calibrator(ref.distortion.RadialTangentialModel())
+    Href = cal._refineHomographies([np.array(H).copy()], [(x, X)])[0]
+    out.update(ex_x=x, ex_X=X, ex_H=np.array(H, dtype=np.float64), ex_Href=np.array(Href, dtype=np.float64))
+    Xk = tl.generateRandomPointsInFrontOfCamera(10)
+    Xk = Xk / ref.mathutils.col(Xk[:, 2])
+    Hexpected = np.array([[410, 10, 320], [20, 385, 240], [0, 0, 1]], dtype=np.float64)
+    xk = (Hexpected @ Xk.T).T
+    xk = (xk / ref.mathutils.col(xk[:, 2]))[:, :2]
+    Hk = ref.linearcalibrate.estimateHomography(xk, Xk[:, :2])
+    assert np.allclose(Hk, Hexpected, atol=1e-3)            # the reference's own assertion
+    out.update(ka_X=Xk, ka_x=xk, ka_Hexpected=Hexpected, ka_H=np.array(Hk, dtype=np.float64))
+    save("g10_real_detections.npz", **out)
 
 
 if __name__ == "__main__":

@@ -8,7 +8,7 @@ for n in 2 4; do
   for ar in torch peer; do
     timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 \
       --master-port $((29600 + n)) bench.py --gpus $n --same-device --backend gloo --allreduce $ar \
-      --workload $wl --views $views --no-cpu-baseline --steps 50 > "$out/rehearsal_${wl}_n${n}_${ar}.log" 2>&1 \
+      --workload $wl --views $views --no-cpu-baseline --no-api --steps 50 > "$out/rehearsal_${wl}_n${n}_${ar}.log" 2>&1 \
       || { echo "n=$n $ar FAILED"; tail -5 "$out/rehearsal_${wl}_n${n}_${ar}.log"; exit 1; }
     python - "$out/rehearsal_${wl}_n${n}_${ar}.log" $n $ar <<'PY'
 import json, sys

@@ -14,7 +14,7 @@ G5="FETCH_SIZE"
 G6="WRITE_SIZE"
 n=1
 for G in "$G1" "$G2" "$G3" "$G4" "$G5" "$G6"; do
-  rocprofv3 --kernel-trace --pmc $G --output-format csv -d $R/gpurun_out/pmc_${TAG}_$n -- python3 $R/bench.py --no-cpu-baseline --steps 10 --warmup 2 --min-seconds 0.05 "$@" > $R/gpurun_out/pmc_${TAG}_$n.log 2>&1
+  rocprofv3 --kernel-trace --pmc $G --output-format csv -d $R/gpurun_out/pmc_${TAG}_$n -- python3 $R/bench.py --no-cpu-baseline --no-api --steps 10 --warmup 2 --min-seconds 0.05 "$@" > $R/gpurun_out/pmc_${TAG}_$n.log 2>&1
   find $R/gpurun_out/pmc_${TAG}_$n -name "*kernel_trace.csv" -delete
   echo "pmc $TAG pass $n done"
   n=$((n+1))

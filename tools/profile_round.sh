@@ -7,12 +7,12 @@ export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/prof
 cd /tmp
 for w in c3 c2 c4 c5; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof/stats_$w -- python3 $R/bench.py --no-cpu-baseline --workload $w > $R/gpurun_out/prof/stats_$w.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof/stats_$w -- python3 $R/bench.py --no-cpu-baseline --no-api --workload $w > $R/gpurun_out/prof/stats_$w.log 2>&1
   find $R/gpurun_out/prof/stats_$w -name "*kernel_trace.csv" -delete      # the stats are what is kept (gpurun_out/ returns <= 64 MiB)
   echo "stats $w done"
 done
 # the driver's own command under the profiler: its fused-kernel average is what BENCH_rNN's roofline must agree with
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof/stats_c3_s20 -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof/stats_c3_s20.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof/stats_c3_s20 -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-api > $R/gpurun_out/prof/stats_c3_s20.log 2>&1
 find $R/gpurun_out/prof/stats_c3_s20 -name "*kernel_trace.csv" -delete
 echo "stats c3 (driver flags) done"
 for w in c3 c5 c2 c4; do
@@ -22,22 +22,22 @@ for w in c3 c5 c2 c4; do
 done
 cd $R
 for w in c2 c4 c5; do
-  python3 bench.py --workload $w --no-cpu-baseline > gpurun_out/prof/bench_$w.json 2> gpurun_out/prof/bench_$w.err
+  python3 bench.py --workload $w --no-cpu-baseline --no-api > gpurun_out/prof/bench_$w.json 2> gpurun_out/prof/bench_$w.err
   echo "bench $w done"
 done
-python3 bench.py --workload c5 --views 1000000 --no-cpu-baseline --steps 20 --warmup 2 > gpurun_out/prof/bench_c5_full.json 2> gpurun_out/prof/bench_c5_full.err
+python3 bench.py --workload c5 --views 1000000 --no-cpu-baseline --no-api --steps 20 --warmup 2 > gpurun_out/prof/bench_c5_full.json 2> gpurun_out/prof/bench_c5_full.err
 echo "bench c5 full done"
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/prof/bench_c3_s20.json 2> gpurun_out/prof/bench_c3_s20.err
 echo "bench c3 driver flags done"
 python3 bench.py > gpurun_out/prof/bench_c3.json 2> gpurun_out/prof/bench_c3.err
 echo "bench c3 done"
-CALIB_FUSED_STREAM=0 python3 bench.py --no-cpu-baseline > gpurun_out/prof/bench_c3_nostream.json 2> gpurun_out/prof/bench_c3_nostream.err
-CALIB_FUSED_STREAM=0 python3 bench.py --no-cpu-baseline --workload c5 > gpurun_out/prof/bench_c5_nostream.json 2> gpurun_out/prof/bench_c5_nostream.err
+CALIB_FUSED_STREAM=0 python3 bench.py --no-cpu-baseline --no-api > gpurun_out/prof/bench_c3_nostream.json 2> gpurun_out/prof/bench_c3_nostream.err
+CALIB_FUSED_STREAM=0 python3 bench.py --no-cpu-baseline --no-api --workload c5 > gpurun_out/prof/bench_c5_nostream.json 2> gpurun_out/prof/bench_c5_nostream.err
 echo "bench without the stream form done"
 # N ranks on ONE GPU over gloo (rehearsal of the N > 1 line: weak + strong blocks, every carrier)
 for n in 2 4; do
   timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29700 + n)) \
-    bench.py --gpus $n --same-device --backend gloo --allreduce all --no-cpu-baseline --steps 20 --warmup 5 --min-seconds 0.2 > gpurun_out/prof/rehearsal_n$n.log 2>&1
+    bench.py --gpus $n --same-device --backend gloo --allreduce all --no-cpu-baseline --no-api --steps 20 --warmup 5 --min-seconds 0.2 > gpurun_out/prof/rehearsal_n$n.log 2>&1
   grep "^{" gpurun_out/prof/rehearsal_n$n.log > gpurun_out/prof/rehearsal_n$n.json
   echo "rehearsal n=$n done"
 done

@@ -5,5 +5,5 @@ w=$1; shift
 export CALIB_FUSED_STREAM=1
 for n in "$@"; do
   export CALIB_STREAM_WAVES=$n
-  python3 $R/bench.py --no-cpu-baseline --workload $w $BENCH_EXTRA 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('waves=$n', '$w', 'ms/step', round(d['ms_per_step'],4), 'fused us', round(d['roofline']['avg_launch_ms']*1e3,2))"
+  python3 $R/bench.py --no-cpu-baseline --no-api --workload $w $BENCH_EXTRA 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('waves=$n', '$w', 'ms/step', round(d['ms_per_step'],4), 'fused us', round(d['roofline']['avg_launch_ms']*1e3,2))"
 done
