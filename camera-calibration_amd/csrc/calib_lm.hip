@@ -449,11 +449,16 @@ PeerExchange next_exchange(calib_handle_s* h) {
     return x;
 }
 
-// shards above this many views load record heads in the coalesced, DPP-broadcast form (kernels.hpp: load_view_head)
-constexpr int kWideHeadViews = 40000;
+// shards above this many views load record heads in the coalesced, DPP-broadcast form (kernels.hpp: load_view_head).
+// Round 4: since a record is six rows (768 B) the broadcast chain behind the loads is 48 DPP moves instead of 54, and on
+// c4's 12 500-view shard the wide update kernel (122 VGPRs, no scratch) is as fast as the narrow one was WITH its 12-byte
+// spill (10.1 vs 10.3 us; the narrow one without the spill, at three workgroups per CU: 12.3 us -- 782 workgroups on 768
+// slots are two rounds). So every shard the small update kernel does not take (> 4 096 views) loads wide; the narrow
+// forms remain for the small shards and on request (CALIB_HEAD_LOADS=narrow).
+constexpr int kWideHeadViews = 4096;
 
-// Large shards, and shards whose views can be two records (stream form: the second record doubles the 27 per-value
-// loads of the narrow form; c3 schur +2.1 us, update +3 us -- seven coalesced rows per record cost nothing extra)
+// Larger shards, and shards whose views can be two records (stream form: the second record doubles the 27 per-value
+// loads of the narrow form; c3 schur +2.1 us, update +3 us -- six coalesced rows per record cost nothing extra)
 bool wide_heads(const calib_handle_s* h) {
     return h->head_loads == 2 || (h->head_loads == 0 && (h->nv > kWideHeadViews || stream_rounds(h)));
 }

@@ -384,7 +384,7 @@ constexpr int kFusedRowChunks = 17;                       // 16 columns + 1 pad 
 // ROWS = points transposed per LDS pass (32: two passes per 64-point batch, half the lanes
 // writing each time; 64: one pass, twice the LDS). WAVES = waves per workgroup.
 template <int MODEL, typename T, int ROWS, int WAVES, bool G44, bool MULTI>
-__global__ __launch_bounds__(64 * WAVES, (sizeof(T) == 4 ? ((MULTI && ModelTraits<MODEL>::C == 16) ? 5 : 6)
+__global__ __launch_bounds__(64 * WAVES, (sizeof(T) == 4 ? (MULTI ? 5 : 6)
                                                              : (ModelTraits<MODEL>::C == 16 ? 4 : 3))) void fused_kernel(const double* __restrict__ P0, const double* __restrict__ P1,
                                                     const typename Pair<T>::type* __restrict__ uv,
                                                     const typename Pair<T>::type* __restrict__ XY,
@@ -1310,7 +1310,9 @@ constexpr int kSchurBlock = 256;
 constexpr int kSchurViewsPerBlock = kSchurBlock / 16;
 
 template <int L, bool WIDE, bool STREAM>
-__global__ __launch_bounds__(kSchurBlock, 4) void schur_kernel(const double* __restrict__ G0,
+// (narrow head loads on stream records -- 27 + 27 per-value loads -- need 136 registers: three workgroups per CU there,
+// instead of four with 20 bytes of scratch per lane; that combination is only ever run on request, CALIB_HEAD_LOADS=narrow)
+__global__ __launch_bounds__(kSchurBlock, (!WIDE && STREAM) ? 3 : 4) void schur_kernel(const double* __restrict__ G0,
                                                             const double* __restrict__ G1,
                                                             const LMState* __restrict__ st,
                                                             const int* __restrict__ view_item0,
@@ -1907,7 +1909,11 @@ __device__ __forceinline__ void finish_view(const double (&V)[21], const double 
 }
 
 template <int L, typename T, bool WIDE, bool STREAM>
-__global__ __launch_bounds__(kSchurThreads, 4) void update_backsub_kernel(
+// (the narrow-load form holds 27 loaded values beside the solve's rows: 130 registers. At four workgroups per CU it
+// spilled 12-20 bytes per lane; three per CU fit without scratch but turn c4's 782 workgroups into two rounds (12.3 us
+// instead of 10.3). Shards beyond the small kernel's reach therefore load wide by default (calib_lm.hip: wide_heads),
+// which needs 122 registers; this form runs on request only, CALIB_HEAD_LOADS=narrow)
+__global__ __launch_bounds__(kSchurThreads, WIDE ? 4 : 3) void update_backsub_kernel(
         const double* __restrict__ G0, const double* __restrict__ G1, const LMState* __restrict__ st_in,
         LMState* __restrict__ st_out, const double* __restrict__ red, const int* __restrict__ view_item0,
         const int* __restrict__ view_ext, int nv, StreamMap sm, double* __restrict__ P0, double* __restrict__ P1,
