@@ -14,6 +14,7 @@
 #pragma once
 #include "point_model.hpp"
 #include <stdint.h>
+#include <type_traits>
 
 namespace calib {
 
@@ -1049,32 +1050,79 @@ __global__ __launch_bounds__(256, CALIB_STREAM_MIN_BLOCKS) void fused_stream_ker
                 SSTAMP(4);
                 const int ng = (p1 - ps >= ROWS ? ROWS : p1 - ps) >> 2;   // groups of the pass (shares are whole groups)
                 const int jb = (vend - ps) >> 2;                // the group a new view starts with (>= ng: none here)
-                if (ng == ROWS / 4 && jb >= ROWS / 4) {
-                    // a whole pass inside one view: every address is the wave's constant base plus an immediate
-                    // the operands of group s + 1 are requested before group s is contracted
-                    T2 ja = src[c], jbb = src[c1];
-                    double ha = h0[0], hc = h2[0];
+                // groups [FROM, TO) of the pass, FROM and TO known at compile time: every address is the wave's constant base
+                // plus an immediate, and the operands of group s + 1 are requested before group s is contracted
+                auto runFixed = [&](auto FROMc, auto TOc) {
+                    constexpr int FROM = decltype(FROMc)::value, TO = decltype(TOc)::value;
+                    if constexpr (FROM < TO) {
+                        T2 ja = src[66 * FROM + c], jbb = src[66 * FROM + c1];
+                        double ha = h0[2 * 66 * FROM], hc = h2[2 * 66 * FROM];
 #pragma unroll
-                    for (int s = 0; s < ROWS / 4; ++s) {
-                        T2 na = ja, nb = jbb;
-                        double nha = ha, nhc = hc;
-                        if (s + 1 < ROWS / 4) {
-                            na = src[66 * (s + 1) + c]; nb = src[66 * (s + 1) + c1];
-                            nha = h0[2 * 66 * (s + 1)]; nhc = h2[2 * 66 * (s + 1)];
+                        for (int s = FROM; s < TO; ++s) {
+                            T2 na = ja, nb = jbb;
+                            double nha = ha, nhc = hc;
+                            if (s + 1 < TO) {
+                                na = src[66 * (s + 1) + c]; nb = src[66 * (s + 1) + c1];
+                                nha = h0[2 * 66 * (s + 1)]; nhc = h2[2 * 66 * (s + 1)];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            contract(ja, jbb, ha, hc);
+                            __builtin_amdgcn_sched_barrier(0);
+                            ja = na; jbb = nb; ha = nha; hc = nhc;
                         }
-                        __builtin_amdgcn_sched_barrier(0);
-                        contract(ja, jbb, ha, hc);
-                        __builtin_amdgcn_sched_barrier(0);
-                        ja = na; jbb = nb; ha = nha; hc = nhc;
                     }
+                };
+                auto nextView = [&]() {                         // the next group is the first of a new view
+                    emitView(slot);
+                    va += 1;
+                    vend += n;
+                    slot = va;
+                };
+                constexpr int NG = ROWS / 4;
+                using std::integral_constant;
+                if (ng == NG && jb >= NG) {
+                    // a whole pass inside one view
+                    runFixed(integral_constant<int, 0>{}, integral_constant<int, NG>{});
 #ifdef CALIB_STREAM_STAMPS
                     asm volatile("" :: "v"(d0u), "v"(d0v), "v"(d1u), "v"(d1v), "v"(d2u));
 #endif
                     SSTAMP(5);
+                } else if (ng == NG) {
+                    // a whole pass with a view boundary before group jb: one straight-line copy of the pass per position of
+                    // the boundary -- groups [0, jb), the finished view's record, groups [jb, 8) -- so that each run keeps
+                    // the operand pipeline of the whole-view pass. (Round 3 entered a switch at the run's first group and
+                    // every group loaded its operands right before its five MFMAs, one exposed LDS latency per group: on c5
+                    // these passes were 36 % of the passes and 19 % of the kernel, twice as dear as the others. Run bounds
+                    // known only at run time do not help: behind a conditional request the compiler cannot count what is
+                    // in flight and waits for everything, lgkmcnt(0), before every group.)
+                    auto boundaryAt = [&](auto JBc) {
+                        constexpr int JB = decltype(JBc)::value;
+                        runFixed(integral_constant<int, 0>{}, integral_constant<int, JB>{});
+#ifdef CALIB_STREAM_STAMPS
+                        asm volatile("" :: "v"(d0u), "v"(d0v), "v"(d1u), "v"(d1v), "v"(d2u));
+#endif
+                        SSTAMP(6);
+                        nextView();
+                        SSTAMP(7);
+                        runFixed(integral_constant<int, JB>{}, integral_constant<int, NG>{});
+#ifdef CALIB_STREAM_STAMPS
+                        asm volatile("" :: "v"(d0u), "v"(d0v), "v"(d1u), "v"(d1v), "v"(d2u));
+#endif
+                        SSTAMP(6);
+                    };
+                    switch (jb) {
+                    case 0: boundaryAt(integral_constant<int, 0>{}); break;
+                    case 1: boundaryAt(integral_constant<int, 1>{}); break;
+                    case 2: boundaryAt(integral_constant<int, 2>{}); break;
+                    case 3: boundaryAt(integral_constant<int, 3>{}); break;
+                    case 4: boundaryAt(integral_constant<int, 4>{}); break;
+                    case 5: boundaryAt(integral_constant<int, 5>{}); break;
+                    case 6: boundaryAt(integral_constant<int, 6>{}); break;
+                    default: boundaryAt(integral_constant<int, 7>{}); break;
+                    }
                 } else {
+                    // the share's last, partial pass (once per wave): groups [from, to) entered through a switch
                     const int sb = jb < ng ? jb : ng;
-                    // groups [from, to) of the pass on immediate offsets: entered at `from`, left at `to` (a rolled loop
-                    // with computed addresses made these passes 2.6 times as dear as the whole-view ones)
                     auto runGroups = [&](int from, int to) {
                         switch (from) {
 #define CALIB_GROUP_CASE(S) case S: if (to <= S) break; contract(src[66 * S + c], src[66 * S + c1], h0[2 * 66 * S], h2[2 * 66 * S]); [[fallthrough]];
@@ -1090,11 +1138,7 @@ __global__ __launch_bounds__(256, CALIB_STREAM_MIN_BLOCKS) void fused_stream_ker
 #endif
                     SSTAMP(6);
                     if (jb < ng) {
-                        // the next group is the first of a new view
-                        emitView(slot);
-                        va += 1;
-                        vend += n;
-                        slot = va;
+                        nextView();
                         SSTAMP(7);
                         runGroups(sb, ng);
 #ifdef CALIB_STREAM_STAMPS
@@ -1165,13 +1209,14 @@ __host__ __device__ __forceinline__ int stream_extra_item(const StreamMap& sm, i
 // 16 lanes per view, working from the head of the view's record(s): lane c < L owns row c of E, lane L the view gradient.
 __device__ __forceinline__ constexpr int tri(int m, int n) { return m * (m + 1) / 2 + n; }
 
-// 1/sqrt(d) for the Cholesky pivots: v_rsq_f64 seed (~2^-26 relative) and two Newton steps -- a
-// chain of 9 dependent operations instead of the ~40 of sqrt() followed by a division
+// 1/sqrt(d) for the Cholesky pivots: v_rsq_f64 seed (~2^-26 relative) and ONE third-order step,
+// r (1 + e/2 + 3 e^2/8) with e = 1 - d r^2 (error ~ e^3: below 2^-70) -- a chain of 6 dependent operations (two Newton
+// steps were 8; sqrt() followed by a division ~40); the six pivots of a 6x6 block are a view's longest chain
 __device__ __forceinline__ double rsqrt_nr(double d) {
-    double r = __builtin_amdgcn_rsq(d);
-    r = r * (1.5 - 0.5 * d * r * r);
-    r = r * (1.5 - 0.5 * d * r * r);
-    return r;
+    const double r = __builtin_amdgcn_rsq(d);
+    const double e = __builtin_fma(-(d * r), r, 1.0);
+    const double p = __builtin_fma(0.375, e, 0.5);
+    return __builtin_fma(r * e, p, r);
 }
 
 // lane N of every 16-lane DPP row to all lanes of that row (row_newbcast, gfx90a+)

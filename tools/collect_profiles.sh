@@ -5,7 +5,7 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd); cd $R
 rnd=${1:-r03}
 for w in c3 c2 c4 c5 c3_s20; do
-  f=$(find gpurun_out/prof/stats_$w -name "*kernel_stats.csv" | head -1); cp $f profiles/${rnd}_${w}_kernel_stats.csv
+  f=$(ls -t $(find gpurun_out/prof/stats_$w -name "*kernel_stats.csv") | head -1); cp $f profiles/${rnd}_${w}_kernel_stats.csv      # the newest: gpurun merges into what earlier rounds left here
 done
 for w in c2 c4 c5 c5_full c3_s20 c3 c3_nostream c5_nostream; do cp gpurun_out/prof/bench_$w.json profiles/${rnd}_${w}_bench.json; done
 cp gpurun_out/prof/rehearsal_n2.json profiles/${rnd}_rehearsal_n2_gloo_one_gpu.json
