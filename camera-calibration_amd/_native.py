@@ -32,6 +32,7 @@ SIGNATURES = {
     "calib_destroy": (ctypes.c_int, [_h]),
     "calib_set_stream": (ctypes.c_int, [_h, ctypes.c_void_p, ctypes.c_int]),
     "calib_set_problem": (ctypes.c_int, [_h, ctypes.c_int64, _c_int64_p, _c_double_p, _c_double_p]),
+    "calib_set_problem_views": (ctypes.c_int, [_h, ctypes.c_int64, _c_int64_p, ctypes.c_void_p, ctypes.c_void_p]),
     "calib_synchronize": (ctypes.c_int, [_h]),
     "calib_set_lm_mode": (ctypes.c_int, [_h, ctypes.c_int]),
     "calib_fused_form": (ctypes.c_int, [_h, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),

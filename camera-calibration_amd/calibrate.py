@@ -86,15 +86,18 @@ class Calibrator:
                             "evaluates the closed-form projection Jacobian inside its kernels and cannot consult an "
                             "injected Jacobian object; use jacobian.ProjectionJacobian (or leave _jac unset)")
         maxIters = operator.index(maxIters)
+        if maxIters <= 0:
+            raise UnboundLocalError("local variable 'Pt_error' referenced before assignment")
         t0 = time.perf_counter()
         Pt = self._composeParameterVector(Ainitial, Winitial, kInitial)
         t1 = time.perf_counter()
-        offs, sensor, model = engine.packDetections(allDetections)
-        t2 = time.perf_counter()
-        sse, P, iters, trace = self.refinePacked(Pt, offs, sensor, model, maxIters, shouldPrint)
+        # the list goes to the device as it is: no np.vstack of the views on the host (src/calibrate.py:277-282 stacks them
+        # per call; here the staged upload gathers from the per-view arrays, engine.ResidentProblem.getFromDetections)
+        eng = self._resident.getFromDetections(allDetections)
+        sse, P, iters, trace = self._refineOn(eng, Pt, maxIters, shouldPrint)
         t3 = time.perf_counter()
         Arefined, Wrefined, kRefined = self._decomposeParameterVector(P)
-        self.lastSeconds.update(compose=t1 - t0, pack=t2 - t1, decompose=time.perf_counter() - t3)
+        self.lastSeconds.update(compose=t1 - t0, decompose=time.perf_counter() - t3)
         return sse, Arefined, Wrefined, kRefined
 
     def refinePacked(self, P0, viewOffsets, sensorPoints, modelPoints, maxIters, shouldPrint=False, sameProblem=False):
@@ -106,6 +109,9 @@ class Calibrator:
         if maxIters <= 0:
             raise UnboundLocalError("local variable 'Pt_error' referenced before assignment")
         eng = self._resident.get(viewOffsets, sensorPoints, modelPoints, sameProblem=sameProblem)
+        return self._refineOn(eng, P0, maxIters, shouldPrint)
+
+    def _refineOn(self, eng, P0, maxIters, shouldPrint):
         t0 = time.perf_counter()
         if not shouldPrint:
             out = eng.refine(P0, maxIters, self._λinitial, self._λmin, self._λmax, self._Pt_error_min)
@@ -138,8 +144,7 @@ class Calibrator:
 
     def _computeReprojectionError(self, P, allDetections):
         """sum over points of ||sensor - projection||^2 (src/calibrate.py:178-183)"""
-        offs, sensor, model = engine.packDetections(allDetections)
-        eng = self._resident.get(offs, sensor, model)
+        eng = self._resident.getFromDetections(allDetections)
         return eng.evaluate(np.asarray(P, dtype=np.float64).ravel())["sse"]
 
     def _computeTotalError(self, ydot, y):

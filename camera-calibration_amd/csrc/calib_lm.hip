@@ -234,10 +234,43 @@ int rccl_fail(const char* what, int rc) {
 constexpr int kUploadThreads = 4;
 constexpr size_t kUploadChunk = (size_t)1 << 20;
 
-int upload_staged(calib_handle_s* h, void* dst, const void* src, size_t bytes) {
+// A (rows, width) float64 matrix on the host: one flat array, or one piece per view (what the reference's callers hold:
+// a list of per-view arrays). The upload reads either; with pieces, getSensorPoints' vstack (src/calibrate.py:277-282)
+// happens inside the staged copy -- nothing is stacked on the host first.
+struct HostRows {
+    const double* flat = nullptr;
+    const double* const* views = nullptr;     // views[i] -> the rows of view i (C-contiguous)
+    const int64_t* offs = nullptr;            // CSR row offsets of the views, nviews + 1 entries
+    int64_t nviews = 0;
+    int width = 0;
+    bool present() const { return flat != nullptr || views != nullptr; }
+    // bytes [off, off + n) of the stacked matrix -> buf
+    void copy(char* buf, size_t off, size_t n) const {
+        if (flat) { std::memcpy(buf, reinterpret_cast<const char*>(flat) + off, n); return; }
+        const size_t rb = (size_t)width * 8;
+        int64_t v = (std::upper_bound(offs, offs + nviews + 1, (int64_t)(off / rb)) - offs) - 1;
+        while (n > 0 && v < nviews) {
+            const size_t b0 = (size_t)offs[v] * rb, b1 = (size_t)offs[v + 1] * rb;
+            if (off < b1) {
+                const size_t take = std::min(n, b1 - off);
+                std::memcpy(buf, reinterpret_cast<const char*>(views[v]) + (off - b0), take);
+                buf += take; off += take; n -= take;
+            }
+            ++v;
+        }
+    }
+};
+
+int upload_staged(calib_handle_s* h, void* dst, const HostRows& src, size_t bytes) {
     if (bytes == 0) return CALIB_OK;
     if (bytes < 2 * kUploadChunk) {
-        HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+        if (src.flat) {
+            HIP_TRY(hipMemcpy(dst, src.flat, bytes, hipMemcpyHostToDevice));
+        } else {
+            std::vector<char> tmp(bytes);
+            src.copy(tmp.data(), 0, bytes);
+            HIP_TRY(hipMemcpy(dst, tmp.data(), bytes, hipMemcpyHostToDevice));
+        }
         return CALIB_OK;
     }
     if (!h->stage_ready) {
@@ -256,7 +289,7 @@ int upload_staged(calib_handle_s* h, void* dst, const void* src, size_t bytes) {
     std::thread workers[kUploadThreads];
     for (int t = 0; t < kUploadThreads; ++t) {
         errs[t] = hipSuccess;
-        workers[t] = std::thread([=, &errs]() {
+        workers[t] = std::thread([=, &errs, &src]() {
             hipError_t e = hipSetDevice(h->device);
             size_t use = 0;
             for (size_t c = (size_t)t; c < nchunks && e == hipSuccess; c += kUploadThreads, ++use) {
@@ -264,7 +297,7 @@ int upload_staged(calib_handle_s* h, void* dst, const void* src, size_t bytes) {
                 const size_t off = c * kUploadChunk, n = std::min(kUploadChunk, bytes - off);
                 if (use >= 2) e = hipEventSynchronize(h->stage_ev[t][b]);      // this buffer's previous DMA is done
                 if (e != hipSuccess) break;
-                std::memcpy(h->stage_buf[t][b], static_cast<const char*>(src) + off, n);
+                src.copy(static_cast<char*>(h->stage_buf[t][b]), off, n);
                 e = hipMemcpyAsync(static_cast<char*>(dst) + off, h->stage_buf[t][b], n, hipMemcpyHostToDevice,
                                    h->stage_stream[t]);
                 if (e == hipSuccess) e = hipEventRecord(h->stage_ev[t][b], h->stage_stream[t]);
@@ -720,8 +753,38 @@ int calib_num_params(calib_handle_t h, int64_t* out_K) {
     return CALIB_OK;
 }
 
+}  // extern "C"
+namespace {
+int set_problem_impl(calib_handle_t h, int64_t num_views, const int64_t* view_offsets, const HostRows& sensor_uv,
+                     const HostRows& model_xyz);
+}
+extern "C" {
+
 int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_offsets,
                       const double* sensor_uv, const double* model_xyz) {
+    HostRows s, m;
+    s.flat = sensor_uv; s.width = 2;
+    m.flat = model_xyz; m.width = 3;
+    return set_problem_impl(h, num_views, view_offsets, s, m);
+}
+
+int calib_set_problem_views(calib_handle_t h, int64_t num_views, const int64_t* view_offsets,
+                            const double* const* sensor_uv_views, const double* const* model_xyz_views) {
+    if (num_views < 0 || !view_offsets) return fail(CALIB_E_INVALID, "bad view_offsets");
+    if (num_views > 0 && !model_xyz_views) return fail(CALIB_E_INVALID, "model_xyz_views is null");
+    for (int64_t i = 0; i < num_views; ++i)
+        if (view_offsets[i + 1] > view_offsets[i] && (!model_xyz_views[i] || (sensor_uv_views && !sensor_uv_views[i])))
+            return fail(CALIB_E_INVALID, "a view with points has a null array");
+    HostRows s, m;
+    s.views = sensor_uv_views; s.offs = view_offsets; s.nviews = num_views; s.width = 2;
+    m.views = model_xyz_views; m.offs = view_offsets; m.nviews = num_views; m.width = 3;
+    return set_problem_impl(h, num_views, view_offsets, s, m);
+}
+
+}  // extern "C"
+namespace {
+int set_problem_impl(calib_handle_t h, int64_t num_views, const int64_t* view_offsets, const HostRows& sensor_uv,
+                     const HostRows& model_xyz) {
     CHECK_H(h);
     if (num_views < 0 || !view_offsets) return fail(CALIB_E_INVALID, "bad view_offsets");
     if (view_offsets[0] != 0) return fail(CALIB_E_INVALID, "view_offsets[0] must be 0");
@@ -729,7 +792,7 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
         if (view_offsets[i + 1] < view_offsets[i])
             return fail(CALIB_E_INVALID, "view_offsets must be non-decreasing");
     const int64_t MN = view_offsets[num_views];
-    if (MN > 0 && !model_xyz) return fail(CALIB_E_INVALID, "model_xyz is null");
+    if (MN > 0 && !model_xyz.present()) return fail(CALIB_E_INVALID, "model_xyz is null");
     if (num_views > 0x7fffffffLL / 8 || MN > (int64_t)1 << 40)
         return fail(CALIB_E_INVALID, "problem too large for one shard");
     SYNC_H(h);
@@ -889,11 +952,11 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
         lap("staged upload xyz");
         int uv_mode = 2;
         const double* uv_in = nullptr;
-        if (sensor_uv && h->dtype == CALIB_DTYPE_F64) {             // already in the device layout
+        if (sensor_uv.present() && h->dtype == CALIB_DTYPE_F64) {   // already in the device layout
             rc = upload_staged(h, h->uv.p, sensor_uv, (size_t)MN * 16);
             if (rc) return rc;
             uv_mode = 0;
-        } else if (sensor_uv) {
+        } else if (sensor_uv.present()) {
             HIP_TRY(uv_stage.alloc((size_t)MN * 2));
             rc = upload_staged(h, uv_stage.p, sensor_uv, (size_t)MN * 16);
             if (rc) return rc;
@@ -917,6 +980,8 @@ int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_o
     h->has_problem = true;
     return CALIB_OK;
 }
+}  // namespace
+extern "C" {
 
 int calib_eval(calib_handle_t h, const double* P, double* out_y, double* out_r, double* out_Jc,
                double* out_sse) {

@@ -46,6 +46,50 @@ def _stack(arrays, width):
     return counts, np.concatenate(arrays, axis=0)
 
 
+_fastpack = False        # the optional CPython helper lib/_fastpack*.so (csrc/fastpack.c): False = not looked for yet
+
+
+def _fastpackModule():
+    global _fastpack
+    if _fastpack is False:
+        import glob
+        import importlib.machinery
+        import importlib.util
+        import os
+        _fastpack = None
+        for path in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "_fastpack*.so")):
+            try:
+                loader = importlib.machinery.ExtensionFileLoader("_fastpack", path)
+                spec = importlib.util.spec_from_loader("_fastpack", loader)
+                mod = importlib.util.module_from_spec(spec)
+                loader.exec_module(mod)
+                _fastpack = mod
+                break
+            except Exception:       # noqa: BLE001 -- built for another interpreter: numpy stacks instead
+                _fastpack = None
+    return _fastpack
+
+
+def viewPointers(allDetections):
+    """list of (sensorPoints (N_i,2), modelPoints (N_i,3)) -> (CSR offsets int64[M+1], sensor addresses uint64[M],
+    model addresses uint64[M]) WITHOUT stacking anything: what calib_set_problem_views gathers from. None when the
+    helper module is not built or a view is not a C-contiguous float64 array of the right width (the caller then
+    stacks with packDetections). The addresses are valid while the caller keeps allDetections alive."""
+    fp = _fastpackModule()
+    if fp is None or len(allDetections) == 0:
+        return None
+    a = fp.view_pointers(allDetections, 0, 2)
+    b = fp.view_pointers(allDetections, 1, 3) if a is not None else None
+    if a is None or b is None:
+        return None
+    if not np.array_equal(a[0], b[0]):
+        i = int(np.flatnonzero(a[0] != b[0])[0])
+        raise ValueError(f"view {i}: expected sensor (N,2) and model (N,3), got ({a[0][i]}, 2) and ({b[0][i]}, 3)")
+    offs = np.zeros(len(allDetections) + 1, dtype=np.int64)
+    np.cumsum(a[0], out=offs[1:])
+    return offs, a[1], b[1]
+
+
 def packDetections(allDetections):
     """list of (sensorPoints (N_i,2), modelPoints (N_i,3)) -> CSR offsets + stacked arrays.
     The stacking is getSensorPoints' vstack (src/calibrate.py:277-282) done once."""
@@ -120,6 +164,22 @@ class RefineEngine:
                                               nat.dptr(sensor), nat.dptr(model)))
         self.M = offs.shape[0] - 1
         self.MN = MN
+        self.viewOffsets = offs
+
+    def setProblemViews(self, viewOffsets, sensorAddresses, modelAddresses):
+        """The same upload from per-view arrays (viewPointers): nothing is stacked on the host, the library's staged
+        upload gathers from the views (calib_set_problem_views). The caller keeps the arrays alive during the call."""
+        offs = np.ascontiguousarray(viewOffsets, dtype=np.int64)
+        M = offs.shape[0] - 1
+        sa = None if sensorAddresses is None else np.ascontiguousarray(sensorAddresses, dtype=np.uint64)
+        ma = np.ascontiguousarray(modelAddresses, dtype=np.uint64)
+        if ma.shape[0] != M or (sa is not None and sa.shape[0] != M):
+            raise ValueError(f"Expected {M} view addresses")
+        nat.check(self._lib.calib_set_problem_views(self._h, M, nat.i64ptr(offs),
+                                                    None if sa is None else ctypes.c_void_p(sa.ctypes.data),
+                                                    ctypes.c_void_p(ma.ctypes.data)))
+        self.M = M
+        self.MN = int(offs[-1])
         self.viewOffsets = offs
 
     def setStream(self, hipStream):
@@ -379,6 +439,32 @@ class ResidentProblem:
                 self._model = np.array(modelPoints, dtype=np.float64, copy=True)
             self._shape = shape + (sensorPoints is not None,)
             self.uploads += 1
+        return self.eng
+
+    def getFromDetections(self, allDetections):
+        """get() for the reference's own argument, a list of per-view (sensor, model) arrays: a large problem is
+        uploaded straight from the views (viewPointers + calib_set_problem_views: no stacked copy on the host); small
+        ones, and lists the helper cannot take, are stacked (packDetections) and go through get().
+        lastSeconds gains "pack": the host time spent stacking / collecting the view addresses."""
+        import time
+        t0 = time.perf_counter()
+        vp = viewPointers(allDetections)
+        if vp is None or int(vp[0][-1]) * 40 <= RESIDENT_COMPARE_LIMIT:
+            offs, sensor, model = packDetections(allDetections)
+            tPack = time.perf_counter() - t0
+            eng = self.get(offs, sensor, model)
+            self.lastSeconds["pack"] = tPack
+            return eng
+        offs, sAddr, mAddr = vp
+        tPack = time.perf_counter() - t0
+        if self.eng is None:
+            self.eng = RefineEngine(self.modelId, self.dtype, self.device)
+        self._offs = self._sensor = self._model = self._shape = None
+        t0 = time.perf_counter()
+        self.eng.setProblemViews(offs, sAddr, mAddr)
+        self.lastSeconds = {"compare": 0.0, "upload": time.perf_counter() - t0, "pack": tPack}
+        self._shape = (offs.shape[0] - 1, int(offs[-1]), True)
+        self.uploads += 1
         return self.eng
 
     def close(self):

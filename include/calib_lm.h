@@ -75,6 +75,13 @@ int calib_synchronize(calib_handle_t h);
  * model_xyz: (MN,3) row-major. Packs to SoA on the device. */
 int calib_set_problem(calib_handle_t h, int64_t num_views, const int64_t* view_offsets,
                       const double* sensor_uv, const double* model_xyz);
+/* The same upload from PER-VIEW arrays, as the reference's callers hold them -- allDetections is a list of
+ * (sensorPoints (N_i,2), modelPoints (N_i,3)) pairs (src/calibrate.py:117-118) that getSensorPoints stacks with np.vstack on
+ * every call (src/calibrate.py:277-282). sensor_uv_views[i] / model_xyz_views[i] point at view i's C-contiguous rows
+ * (view_offsets[i+1] - view_offsets[i] of them; NULL allowed for an empty view; sensor_uv_views itself may be NULL).
+ * Nothing is stacked on the host: the staged upload gathers from the views straight into its pinned buffers. */
+int calib_set_problem_views(calib_handle_t h, int64_t num_views, const int64_t* view_offsets,
+                            const double* const* sensor_uv_views, const double* const* model_xyz_views);
 
 /* How an LM round forms the per-view normal equations:
  *   CALIB_LM_FUSED       one kernel evaluates the 2 x C Jacobian blocks and contracts them with

@@ -294,6 +294,55 @@ def test_resident_problem_notices_in_place_changes_of_the_callers_arrays():
     fresh.close()
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_upload_from_per_view_arrays_equals_the_stacked_upload(dtype):
+    """calib_set_problem_views gathers the reference's list of per-view arrays (src/calibrate.py:117-118, stacked by
+    getSensorPoints at :277-282) inside the staged upload: bit for bit the device state of calib_set_problem on the
+    np.vstack of the same views -- ragged views, an empty one, chunk borders inside rows and views (16 MB: staged
+    path), and the small direct path."""
+    from camera_calibration_amd import engine, synthetic
+    g = loadGolden("g3_unittest15.npz")
+    offs = g["viewOffsets"]
+    small = [(g["sensorPoints"][a:b].copy(), g["modelPoints"][a:b].copy()) for a, b in zip(offs[:-1], offs[1:])]
+    sh = synthetic.makeShard("c3", viewStart=3, numViews=2000, noiseSigma=0.05)
+    o2 = sh["viewOffsets"]
+    big = [(sh["sensorPoints"][a:b].copy(), sh["modelPoints"][a:b].copy()) for a, b in zip(o2[:-1], o2[1:])]
+    for name, dets, P in (("radtan", small, g["P0"]), ("fisheye", big, sh["P0"])):
+        vp = engine.viewPointers(dets)
+        assert vp is not None
+        flat = engine.packDetections(dets)
+        a, b = cca.RefineEngine(name, dtype), cca.RefineEngine(name, dtype)
+        a.setProblem(*flat)
+        b.setProblemViews(*vp)
+        ea, eb = a.evaluate(P, wantY=True, wantR=True), b.evaluate(P, wantY=True, wantR=True)
+        assert ea["sse"] == eb["sse"] and np.array_equal(ea["y"], eb["y"]) and np.array_equal(ea["r"], eb["r"])
+        ra, rb = a.refine(P, 6), b.refine(P, 6)
+        assert ra[0] == rb[0] and np.array_equal(ra[1], rb[1]) and np.array_equal(ra[3], rb[3])
+        a.close()
+        b.close()
+    # an empty view in the list (legal for the upload; the refinement itself rejects it as singular, like a flat upload)
+    withEmpty = small[:2] + [(np.empty((0, 2)), np.empty((0, 3)))] + small[2:]
+    vp = engine.viewPointers(withEmpty)
+    e = cca.RefineEngine("radtan", dtype)
+    e.setProblemViews(*vp)
+    P = np.concatenate((g["P0"][:10 + 12], np.zeros(6), g["P0"][10 + 12:]))
+    f = cca.RefineEngine("radtan", dtype)
+    f.setProblem(*engine.packDetections(withEmpty))
+    assert e.evaluate(P)["sse"] == f.evaluate(P)["sse"]
+    e.close()
+    f.close()
+    # and through the reference-shaped call: a large list goes up without a host-side stack, same answer as refinePacked
+    cal = cca.Calibrator(cca.FisheyeModel(), dtype=dtype)
+    A0, W0, k0 = cal._decomposeParameterVector(sh["P0"])
+    s1 = cal.refineCalibrationParameters(A0, W0, k0, big, 5)
+    assert cal.lastSeconds["upload"] > 0 and cal._resident._model is None
+    cal2 = cca.Calibrator(cca.FisheyeModel(), dtype=dtype)
+    s2 = cal2.refinePacked(cal2._composeParameterVector(A0, W0, k0), *engine.packDetections(big), 5)
+    assert s1[0] == s2[0] and np.array_equal(s1[3], cal2._decomposeParameterVector(s2[1])[2])
+    cal.close()
+    cal2.close()
+
+
 def test_resident_problem_large_problems_are_uploaded_not_compared(monkeypatch):
     """Above engine.RESIDENT_COMPARE_LIMIT a problem is uploaded again on every call (an upload is cheaper than a
     host compare and can never be stale), unless the caller vouches for it with sameProblem=True."""

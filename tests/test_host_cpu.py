@@ -170,6 +170,28 @@ def test_pack_detections_fast_path_and_fallback():
     assert np.array_equal(om, offs) and np.array_equal(mm, m)
 
 
+def test_view_pointers_of_a_detection_list():
+    """engine.viewPointers (csrc/fastpack.c): per-view row counts and data addresses of the reference's allDetections
+    list, for calib_set_problem_views to gather from -- or None (numpy stacks instead) when a view is not a C-contiguous
+    float64 array of the right width; mismatched counts are the ValueError packDetections raises."""
+    assert engine._fastpackModule() is not None, "lib/_fastpack*.so is built by csrc/Makefile (__graft_entry__.build())"
+    rng = np.random.default_rng(4)
+    ns = [5, 0, 17, 4]
+    dets = [(rng.random((n, 2)), rng.random((n, 3))) for n in ns]
+    offs, sa, ma = engine.viewPointers(dets)
+    assert list(offs) == [0, 5, 5, 22, 26] and sa.dtype == np.uint64 and ma.dtype == np.uint64
+    for i, (s_, m_) in enumerate(dets):
+        assert int(sa[i]) == s_.ctypes.data and int(ma[i]) == m_.ctypes.data
+    assert engine.viewPointers([(d[0], d[1]) for d in dets][:0]) is None                     # nothing to point at
+    assert engine.viewPointers([(dets[0][0].tolist(), dets[0][1])]) is None                  # not an ndarray
+    assert engine.viewPointers([(dets[0][0].astype(np.float32), dets[0][1])]) is None        # not float64
+    assert engine.viewPointers([(dets[0][0][::2], dets[0][1][::2])]) is None                 # not contiguous
+    assert engine.viewPointers([(dets[0][1], dets[0][1])]) is None                           # wrong width
+    assert engine.viewPointers([dets[0][0]]) is None                                         # not a pair
+    with pytest.raises(ValueError, match="view 1"):
+        engine.viewPointers([dets[0], (np.zeros((3, 2)), np.zeros((4, 3)))])
+
+
 def test_detections_json_roundtrip(tmp_path):
     # tests/test_dataset.py:70-90: exportDetections / createDetectionsFromPath, same JSON schema
     from camera_calibration_amd import dataset
