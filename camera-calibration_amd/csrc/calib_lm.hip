@@ -121,6 +121,7 @@ struct calib_handle_s {
     int uniform_n = 0;            // > 0: every item is one whole view of exactly this many points, in order (item i = view i = points [i n, (i+1) n))
     int head_loads = 0;           // per-view kernels' record-head loads: 0 = by shard size, 1 = one load per value, 2 = coalesced + DPP (CALIB_HEAD_LOADS)
     int items_per_wave = 0;       // fused kernel, short uniform items: 0 = chosen per shard (CALIB_ITEMS_PER_WAVE)
+    int upd_lane_views = 0;       // shards from this many views on take update_backsub_lane_kernel (CALIB_UPD_LANE_VIEWS)
     int gram_form = 0;            // fp64 fused kernel: 0 = chosen per shard, 1 = 16x16x4 tiles, 2 = 4x4x4 blocks (CALIB_GRAM_FORM)
     int stream_mode = -1;         // fused_stream_kernel: -1 = chosen per shard, 0 = never, 1 = whenever the shard allows it (CALIB_FUSED_STREAM)
     int stream_waves_env = 0;     // > 0: waves of the stream launch (CALIB_STREAM_WAVES); 0 = the chip's wave slots
@@ -533,6 +534,10 @@ LMState* st_next(calib_handle_s* h) { return h->st.p + ((h->rounds_enqueued + 1)
 
 // shards of at most this many views take the latency-oriented form of the update kernel (kernels.hpp)
 constexpr int kUpdSmallViews = 4096;
+// shards of at least this many views take the one-lane-per-view form (a wave per 64 views: it needs many to fill the chip).
+// tools/sweep_upd_lane.sh, update kernel us, 16 lanes per view / one lane per view: 10 000 views 8.9 / 15.0 - 12 500 (fp32)
+// 10.0 / 11.5 - 16 384: 11.2 / 12.4 - 32 768: 19.0 / 13.3 - 65 536: 29.7 / 17.6 - 125 000: 47.5 / 30.5
+constexpr int kUpdLaneViews = 24576;
 
 template <int L, typename T>
 int launch_update_backsub_t(calib_handle_s* h) {
@@ -546,6 +551,18 @@ int launch_update_backsub_t(calib_handle_s* h) {
         if (stream_rounds(h)) launchSmall(update_backsub_small_kernel<L, T, true>);
         else launchSmall(update_backsub_small_kernel<L, T, false>);
         LAUNCHED(h, "update_backsub_small_kernel");
+        return CALIB_OK;
+    }
+    if (h->nv >= h->upd_lane_views && h->head_loads == 0) {
+        const int blocks = std::max(1, std::min(12 * h->num_cus, (h->nv + kSchurThreads - 1) / kSchurThreads));
+        auto launchLane = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kSchurThreads), 0, h->stream,
+                               h->G[0].p, h->G[1].p, st_cur(h), st_next(h), h->red, view_items(h), h->view_ext.p, h->nv,
+                               stream_map(h), h->P[0].p, h->P[1].p, h->trace.p, reinterpret_cast<T*>(h->VC.p));
+        };
+        if (stream_rounds(h)) launchLane(update_backsub_lane_kernel<L, T, true>);
+        else launchLane(update_backsub_lane_kernel<L, T, false>);
+        LAUNCHED(h, "update_backsub_lane_kernel");
         return CALIB_OK;
     }
     const int per = kSchurThreads / 16;
@@ -648,6 +665,8 @@ int calib_create(int model, int dtype, int device_id, calib_handle_t* out_handle
     if (const char* e = std::getenv("CALIB_LM_MODE")) h->lm_mode = std::atoi(e) ? CALIB_LM_TWO_KERNEL : CALIB_LM_FUSED;
     if (const char* e = std::getenv("CALIB_HEAD_LOADS")) h->head_loads = std::strcmp(e, "narrow") == 0 ? 1 : (std::strcmp(e, "wide") == 0 ? 2 : 0);
     if (const char* e = std::getenv("CALIB_ITEMS_PER_WAVE")) h->items_per_wave = std::max(0, std::min(16, std::atoi(e)));
+    h->upd_lane_views = kUpdLaneViews;
+    if (const char* e = std::getenv("CALIB_UPD_LANE_VIEWS")) h->upd_lane_views = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("CALIB_GRAM_FORM")) h->gram_form = std::strcmp(e, "tile") == 0 ? 1 : (std::strcmp(e, "block") == 0 ? 2 : 0);
     if (const char* e = std::getenv("CALIB_FUSED_STREAM")) h->stream_mode = std::atoi(e) > 0 ? 1 : (std::atoi(e) == 0 ? 0 : -1);
     if (const char* e = std::getenv("CALIB_STREAM_WAVES")) h->stream_waves_env = std::max(0, std::atoi(e));

@@ -2074,6 +2074,123 @@ __global__ __launch_bounds__(kUpdThreads) void update_backsub_small_kernel(
     finish_view<L, T>(V, invd, z, coef, c, v, view_ext, cur ? P1 : P0, cur ? P0 : P1, VC);
 }
 
+// The same round step for LARGE shards, one LANE per view (round 4). With 16 lanes per view every group repeats the
+// view's 6x6 Cholesky for its own right-hand side and hands 27 head values round by DPP; per four views that is ~420
+// vector instructions, and on c5's 125 000-view shard the kernel was bound by fp64 issue (45 us), not by its 96 MB of
+// records. Here a lane owns a view: it reads the view's six record rows itself (eight 16-byte loads per row: the
+// lane's own 128-byte line), folds the shared step into the right-hand side on the fly -- rhs = g_v - E^T dc, dc
+// wave-uniform in scalar registers -- factors V + lam diag(V) once, substitutes forward and back, writes the view's
+// part of the next candidate and the candidate's view constants. ~500 vector instructions per SIXTY-FOUR views.
+// Needs many views to fill the chip (a wave per 64 of them): the host takes it above kUpdLaneViews.
+template <int L, typename T, bool STREAM>
+__global__ __launch_bounds__(kSchurThreads, 3) void update_backsub_lane_kernel(
+        const double* __restrict__ G0, const double* __restrict__ G1, const LMState* __restrict__ st_in,
+        LMState* __restrict__ st_out, const double* __restrict__ red, const int* __restrict__ view_item0,
+        const int* __restrict__ view_ext, int nv, StreamMap sm, double* __restrict__ P0, double* __restrict__ P1,
+        double* __restrict__ trace, T* __restrict__ VC) {
+    const int tid = threadIdx.x, c = tid & 15;
+    const bool writer = blockIdx.x == 0 && tid < 16;
+    __shared__ double sdec[L + 3];
+    {
+        int cur0 = 0;
+        double lam0 = 0.0, dc0[L];
+        if (tid < 16) {
+            const bool go = lm_update_step<L>(st_in, st_out, red, P0, P1, trace, writer, c, cur0, lam0, dc0);
+            if (c == 0) { sdec[0] = go ? 1.0 : 0.0; sdec[1] = (double)cur0; sdec[2] = lam0; }
+            if (c < L) {
+                double dci = 0.0;
+#pragma unroll
+                for (int j = 0; j < L; ++j) if (j == c) dci = dc0[j];
+                sdec[3 + c] = dci;
+            }
+        }
+    }
+    __syncthreads();
+    if (sdec[0] == 0.0) return;
+    const int cur = (int)sdec[1];
+    const double lam = sdec[2];
+    double dc[L];                                              // wave-uniform: scalar registers
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        const double t = sdec[3 + j];
+        dc[j] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(t)),
+                                 __builtin_amdgcn_readfirstlane(__double2loint(t)));
+    }
+    const double* G = cur ? G1 : G0;
+    const double* Pc = cur ? P1 : P0;
+    double* Pn = cur ? P0 : P1;
+    for (int v = blockIdx.x * kSchurThreads + tid; v < nv; v += gridDim.x * kSchurThreads) {
+        double V[21], gv[6], acc[6];
+#pragma unroll
+        for (int i = 0; i < 21; ++i) V[i] = 0.0;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) { gv[m] = 0.0; acc[m] = 0.0; }
+        // one record: rows m = 0..5 of [E^T | V], g_v in V's upper triangle (gvSlot)
+        auto addRecord = [&](const double* __restrict__ g) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                const double2* row = reinterpret_cast<const double2*>(g + kGRows + m * 16);
+                double r[16];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const double2 t = row[q]; r[2 * q] = t.x; r[2 * q + 1] = t.y; }
+#pragma unroll
+                for (int j = 0; j < L; ++j) acc[m] = __builtin_fma(r[j], dc[j], acc[m]);
+#pragma unroll
+                for (int n = 0; n <= m; ++n) V[tri(m, n)] += r[L + n];
+                if (m == 0) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) gv[j] += r[L + 1 + j];
+                }
+                if (m == 1) gv[5] += r[L + 2];
+            }
+        };
+        const int i0 = view_item0 ? view_item0[v] : v, i1 = view_item0 ? view_item0[v + 1] : v + 1;
+        for (int it = i0; it < i1; ++it) addRecord(G + (int64_t)it * kGStride);
+        if (STREAM) {
+            const int e = stream_extra_item(sm, v);
+            if (e >= 0) addRecord(G + (int64_t)e * kGStride);
+        }
+        double rhs[6], invd[6], z[6], d[6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) rhs[m] = gv[m] - acc[m];
+        eliminate(V, rhs, lam, invd, z);
+#pragma unroll
+        for (int m = 5; m >= 0; --m) {                          // Lc^T d = z
+            double t = z[m];
+#pragma unroll
+            for (int n = m + 1; n < 6; ++n) t -= V[tri(n, m)] * d[n];
+            d[m] = t * invd[m];
+        }
+        const int64_t o = L + 6 * (int64_t)view_ext[v];
+        double en[6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) { en[m] = Pc[o + m] + d[m]; Pn[o + m] = en[m]; }
+        // view constants of the candidate (layout of view_setup_kernel)
+        const double deg = 0.017453292519943295;
+        double sn[3], cs[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double th = en[a] * deg;
+            sincos(th, &sn[a], &cs[a]);
+            if (fabs(th) <= 1e-8) { sn[a] = 0.0; cs[a] = 1.0; }
+        }
+        const double sx = sn[0], cx = cs[0], sy = sn[1], cy = cs[1], sz = sn[2], cz = cs[2];
+        const double o18[18] = {cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx,
+                                sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx,
+                                -sy, cy * sx, cy * cx, en[3], en[4], en[5],
+                                deg * cz * cy, deg * sz * cy, -deg * sy, -deg * sz, deg * cz, 0.0};
+        T* dst = VC + (int64_t)v * kViewStride;
+        using T2 = typename Pair<T>::type;
+#pragma unroll
+        for (int j = 0; j < kViewStride / 2; ++j) {             // 18 values: 144 / 72 bytes, 16- / 8-byte aligned pairs
+            T2 t;
+            t.x = (T)o18[2 * j];
+            t.y = (T)o18[2 * j + 1];
+            reinterpret_cast<T2*>(dst)[j] = t;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- per-view homography LM
 // Calibrator._refineHomography (src/calibrate.py:69-111) for every view at once: 16 lanes per
 // view run the whole 20-iteration loop (lambda 1e-3, /10 on an accepted step, x10 otherwise,

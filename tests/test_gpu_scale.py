@@ -368,6 +368,54 @@ def test_random_ragged_views_vs_c_oracle(name, model, seed, form, monkeypatch):
         eng.close()
 
 
+@pytest.mark.parametrize("name,dtype,stream", [("radtan", "f64", "0"), ("fisheye", "f64", "1"), ("radtan", "f32", "0")])
+def test_one_lane_per_view_update_kernel_matches_the_16_lane_form(name, dtype, stream, monkeypatch):
+    """update_backsub_lane_kernel (large shards: a lane owns a view, rhs = g_v - E^T dc folded in while the lane reads its
+    record rows) against update_backsub_kernel (16 lanes per view) on the same shards -- ragged views incl. several items
+    per view (> 512 points), an empty view, stream-form shards with cut views (two records per view), fp32 storage --
+    and against the C oracle: same accept / reject sequence, candidates equal to rounding of another summation order.
+    Arithmetic: src/calibrate.py:152,162 (the step and P + delta), src/mathutils.py:36-51 (the candidate's rotations)."""
+    from oracle import c_oracle
+    model = orc.RADTAN if name == "radtan" else orc.FISHEYE
+    L = orc.numShared(model)
+    rng = np.random.default_rng(11)
+    if stream == "1":
+        cfg = dict(synthetic.CONFIGS["c3"])
+        sh = synthetic.makeShard(cfg, viewStart=5, numViews=700, noiseSigma=0.05)
+        offs, sensor, pts, P0 = sh["viewOffsets"], sh["sensorPoints"], sh["modelPoints"], sh["P0"]
+        monkeypatch.setenv("CALIB_STREAM_WAVES", "97")           # 700 views x 50 groups on 97 waves: most views are cut
+    else:
+        sizes = np.concatenate(([3, 64, 513, 700, 1200], rng.integers(3, 150, 70)))
+        rng.shuffle(sizes)
+        M = sizes.shape[0]
+        offs = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+        cfg = synthetic.CONFIGS["c2"]
+        corners = synthetic.checkerboardCorners(25, 18, 0.02)
+        W = synthetic.sampleBoardPosesInCamera(corners, np.arange(300, 300 + M))
+        Ptrue = synthetic.composeP(cfg["A"], W, cfg["k"])
+        pts = np.vstack([np.column_stack((rng.uniform(0, 0.48, n), rng.uniform(0, 0.34, n), rng.uniform(-0.01, 0.01, n))) for n in sizes])
+        sensor = c_oracle.evaluate(model, Ptrue, offs, None, pts)["y"] + rng.normal(0, 0.05, (int(offs[-1]), 2))
+        P0 = Ptrue * (1 + 1e-3 * rng.standard_normal(Ptrue.shape[0]))
+    monkeypatch.setenv("CALIB_FUSED_STREAM", stream)
+    outs = {}
+    for lanes in ("1", "1000000000"):
+        monkeypatch.setenv("CALIB_UPD_LANE_VIEWS", lanes)        # read at calib_create
+        eng = cca.RefineEngine(name, dtype)
+        eng.setProblem(offs, sensor, pts)
+        assert (eng.fusedForm()[0] > 0) == (stream == "1")
+        outs[lanes] = eng.refine(P0, 12)
+        eng.close()
+    (sseA, PA, itA, trA), (sseB, PB, itB, trB) = outs["1"], outs["1000000000"]
+    tol = 1e-10 if dtype == "f64" else 1e-5
+    n = min(6, itA, itB)
+    assert np.array_equal(trA[:n, 3], trB[:n, 3]) and np.allclose(trA[:n, 1:3], trB[:n, 1:3], rtol=1e-9 if dtype == "f64" else 1e-5)
+    assert abs(sseA - sseB) <= 1e-7 * sseB and relIntr(PA, PB, L) < tol * 100
+    assert np.abs(PA - PB).max() <= tol * 1e3 * max(1.0, np.abs(PB).max())
+    if dtype == "f64" and c_oracle.available():
+        sseO, PO, trO = c_oracle.refine(model, P0, offs, sensor, pts, 12)
+        assert np.array_equal(trA[:n, 3], trO[:n, 3]) and relIntr(PA, PO, L) < 1e-7
+
+
 def test_nan_candidate_is_rejected_not_propagated():
     """A step that sends a point behind the camera / to NaN must be rejected (IEEE `<` is false,
     src/calibrate.py:161) and leave the parameters finite."""
