@@ -122,6 +122,7 @@ struct calib_handle_s {
     int head_loads = 0;           // per-view kernels' record-head loads: 0 = by shard size, 1 = one load per value, 2 = coalesced + DPP (CALIB_HEAD_LOADS)
     int items_per_wave = 0;       // fused kernel, short uniform items: 0 = chosen per shard (CALIB_ITEMS_PER_WAVE)
     int upd_lane_views = 0;       // shards from this many views on take update_backsub_lane_kernel (CALIB_UPD_LANE_VIEWS)
+    int upd_small_views = 0;      // shards up to this many views take update_backsub_small_kernel (CALIB_UPD_SMALL_VIEWS)
     int gram_form = 0;            // fp64 fused kernel: 0 = chosen per shard, 1 = 16x16x4 tiles, 2 = 4x4x4 blocks (CALIB_GRAM_FORM)
     int stream_mode = -1;         // fused_stream_kernel: -1 = chosen per shard, 0 = never, 1 = whenever the shard allows it (CALIB_FUSED_STREAM)
     int stream_waves_env = 0;     // > 0: waves of the stream launch (CALIB_STREAM_WAVES); 0 = the chip's wave slots
@@ -541,7 +542,7 @@ constexpr int kUpdLaneViews = 24576;
 
 template <int L, typename T>
 int launch_update_backsub_t(calib_handle_s* h) {
-    if (h->nv <= kUpdSmallViews) {
+    if (h->nv <= h->upd_small_views) {
         const int blocks = std::max(1, (h->nv + kUpdViewsPerBlock - 1) / kUpdViewsPerBlock);    // one view per 16-lane group
         auto launchSmall = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kUpdThreads), 0, h->stream,
@@ -667,6 +668,8 @@ int calib_create(int model, int dtype, int device_id, calib_handle_t* out_handle
     if (const char* e = std::getenv("CALIB_ITEMS_PER_WAVE")) h->items_per_wave = std::max(0, std::min(16, std::atoi(e)));
     h->upd_lane_views = kUpdLaneViews;
     if (const char* e = std::getenv("CALIB_UPD_LANE_VIEWS")) h->upd_lane_views = std::max(1, std::atoi(e));
+    h->upd_small_views = kUpdSmallViews;
+    if (const char* e = std::getenv("CALIB_UPD_SMALL_VIEWS")) h->upd_small_views = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("CALIB_GRAM_FORM")) h->gram_form = std::strcmp(e, "tile") == 0 ? 1 : (std::strcmp(e, "block") == 0 ? 2 : 0);
     if (const char* e = std::getenv("CALIB_FUSED_STREAM")) h->stream_mode = std::atoi(e) > 0 ? 1 : (std::atoi(e) == 0 ? 0 : -1);
     if (const char* e = std::getenv("CALIB_STREAM_WAVES")) h->stream_waves_env = std::max(0, std::atoi(e));

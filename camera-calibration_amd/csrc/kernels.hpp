@@ -1313,8 +1313,7 @@ __device__ __forceinline__ void load_view_head(const double* __restrict__ G, int
 // the strictly lower part of V is the factor Lc, invd the reciprocal of its diagonal -- and the
 // forward substitution z = Lc^-1 b of this lane's right-hand side. Returns false when a pivot is
 // not positive.
-__device__ __forceinline__ bool eliminate(double (&V)[21], const double (&b)[6], double lam,
-                                          double (&invd)[6], double (&z)[6]) {
+__device__ __forceinline__ bool cholesky6(double (&V)[21], double lam, double (&invd)[6]) {
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -1332,6 +1331,10 @@ __device__ __forceinline__ bool eliminate(double (&V)[21], const double (&b)[6],
             V[tri(i, j)] = t * inv;
         }
     }
+    return ok;
+}
+__device__ __forceinline__ void forward6(const double (&V)[21], const double (&invd)[6], const double (&b)[6],
+                                         double (&z)[6]) {
 #pragma unroll
     for (int m = 0; m < 6; ++m) {
         double t = b[m];
@@ -1339,7 +1342,54 @@ __device__ __forceinline__ bool eliminate(double (&V)[21], const double (&b)[6],
         for (int n = 0; n < m; ++n) t -= V[tri(m, n)] * z[n];
         z[m] = t * invd[m];
     }
+}
+__device__ __forceinline__ bool eliminate(double (&V)[21], const double (&b)[6], double lam,
+                                          double (&invd)[6], double (&z)[6]) {
+    const bool ok = cholesky6(V, lam, invd);
+    forward6(V, invd, b, z);
     return ok;
+}
+
+// Lc^T d = z, then the view's part of the next candidate P and the candidate's view constants (one lane per view)
+template <int L, typename T>
+__device__ __forceinline__ void finish_view_lane(const double (&V)[21], const double (&invd)[6], const double (&z)[6],
+                                                 int v, const int* __restrict__ view_ext, const double* __restrict__ Pc,
+                                                 double* __restrict__ Pn, T* __restrict__ VC) {
+    double d[6];
+#pragma unroll
+    for (int m = 5; m >= 0; --m) {
+        double t = z[m];
+#pragma unroll
+        for (int n = m + 1; n < 6; ++n) t -= V[tri(n, m)] * d[n];
+        d[m] = t * invd[m];
+    }
+    const int64_t o = L + 6 * (int64_t)view_ext[v];
+    double en[6];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) { en[m] = Pc[o + m] + d[m]; Pn[o + m] = en[m]; }
+    // view constants of the candidate (layout of view_setup_kernel)
+    const double deg = 0.017453292519943295;
+    double sn[3], cs[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double th = en[a] * deg;
+        sincos(th, &sn[a], &cs[a]);
+        if (fabs(th) <= 1e-8) { sn[a] = 0.0; cs[a] = 1.0; }
+    }
+    const double sx = sn[0], cx = cs[0], sy = sn[1], cy = cs[1], sz = sn[2], cz = cs[2];
+    const double o18[18] = {cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx,
+                            sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx,
+                            -sy, cy * sx, cy * cx, en[3], en[4], en[5],
+                            deg * cz * cy, deg * sz * cy, -deg * sy, -deg * sz, deg * cz, 0.0};
+    T* dst = VC + (int64_t)v * kViewStride;
+    using T2 = typename Pair<T>::type;
+#pragma unroll
+    for (int j = 0; j < kViewStride / 2; ++j) {                 // 18 values: 144 / 72 bytes, 16- / 8-byte aligned pairs
+        T2 t;
+        t.x = (T)o18[2 * j];
+        t.y = (T)o18[2 * j + 1];
+        reinterpret_cast<T2*>(dst)[j] = t;
+    }
 }
 
 // ---------------------------------------------------------------- schur partials
@@ -2150,44 +2200,11 @@ __global__ __launch_bounds__(kSchurThreads, 3) void update_backsub_lane_kernel(
             const int e = stream_extra_item(sm, v);
             if (e >= 0) addRecord(G + (int64_t)e * kGStride);
         }
-        double rhs[6], invd[6], z[6], d[6];
+        double rhs[6], invd[6], z[6];
 #pragma unroll
         for (int m = 0; m < 6; ++m) rhs[m] = gv[m] - acc[m];
         eliminate(V, rhs, lam, invd, z);
-#pragma unroll
-        for (int m = 5; m >= 0; --m) {                          // Lc^T d = z
-            double t = z[m];
-#pragma unroll
-            for (int n = m + 1; n < 6; ++n) t -= V[tri(n, m)] * d[n];
-            d[m] = t * invd[m];
-        }
-        const int64_t o = L + 6 * (int64_t)view_ext[v];
-        double en[6];
-#pragma unroll
-        for (int m = 0; m < 6; ++m) { en[m] = Pc[o + m] + d[m]; Pn[o + m] = en[m]; }
-        // view constants of the candidate (layout of view_setup_kernel)
-        const double deg = 0.017453292519943295;
-        double sn[3], cs[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double th = en[a] * deg;
-            sincos(th, &sn[a], &cs[a]);
-            if (fabs(th) <= 1e-8) { sn[a] = 0.0; cs[a] = 1.0; }
-        }
-        const double sx = sn[0], cx = cs[0], sy = sn[1], cy = cs[1], sz = sn[2], cz = cs[2];
-        const double o18[18] = {cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx,
-                                sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx,
-                                -sy, cy * sx, cy * cx, en[3], en[4], en[5],
-                                deg * cz * cy, deg * sz * cy, -deg * sy, -deg * sz, deg * cz, 0.0};
-        T* dst = VC + (int64_t)v * kViewStride;
-        using T2 = typename Pair<T>::type;
-#pragma unroll
-        for (int j = 0; j < kViewStride / 2; ++j) {             // 18 values: 144 / 72 bytes, 16- / 8-byte aligned pairs
-            T2 t;
-            t.x = (T)o18[2 * j];
-            t.y = (T)o18[2 * j + 1];
-            reinterpret_cast<T2*>(dst)[j] = t;
-        }
+        finish_view_lane<L, T>(V, invd, z, v, view_ext, Pc, Pn, VC);
     }
 }
 

@@ -398,19 +398,25 @@ def test_one_lane_per_view_update_kernel_matches_the_16_lane_form(name, dtype, s
         P0 = Ptrue * (1 + 1e-3 * rng.standard_normal(Ptrue.shape[0]))
     monkeypatch.setenv("CALIB_FUSED_STREAM", stream)
     outs = {}
-    for lanes in ("1", "1000000000"):
-        monkeypatch.setenv("CALIB_UPD_LANE_VIEWS", lanes)        # read at calib_create
+    monkeypatch.setenv("CALIB_UPD_SMALL_VIEWS", "0")             # these shards are small: keep them off the small-shard kernel
+    # (knobs are read at calib_create) lane: update_backsub_lane_kernel; wide16: update_backsub_kernel, 16 lanes per view
+    for form, lanes in (("lane", "1"), ("wide16", "1000000000")):
+        monkeypatch.setenv("CALIB_UPD_LANE_VIEWS", lanes)
         eng = cca.RefineEngine(name, dtype)
         eng.setProblem(offs, sensor, pts)
         assert (eng.fusedForm()[0] > 0) == (stream == "1")
-        outs[lanes] = eng.refine(P0, 12)
+        outs[form] = eng.refine(P0, 12)
         eng.close()
-    (sseA, PA, itA, trA), (sseB, PB, itB, trB) = outs["1"], outs["1000000000"]
+    sseB, PB, itB, trB = outs["wide16"]
     tol = 1e-10 if dtype == "f64" else 1e-5
+    for form in ("lane",):
+        sseA, PA, itA, trA = outs[form]
+        n = min(6, itA, itB)
+        assert np.array_equal(trA[:n, 3], trB[:n, 3]) and np.allclose(trA[:n, 1:3], trB[:n, 1:3], rtol=1e-9 if dtype == "f64" else 1e-5), form
+        assert abs(sseA - sseB) <= 1e-7 * sseB and relIntr(PA, PB, L) < tol * 100, form
+        assert np.abs(PA - PB).max() <= tol * 1e3 * max(1.0, np.abs(PB).max()), form
+    sseA, PA, itA, trA = outs["lane"]
     n = min(6, itA, itB)
-    assert np.array_equal(trA[:n, 3], trB[:n, 3]) and np.allclose(trA[:n, 1:3], trB[:n, 1:3], rtol=1e-9 if dtype == "f64" else 1e-5)
-    assert abs(sseA - sseB) <= 1e-7 * sseB and relIntr(PA, PB, L) < tol * 100
-    assert np.abs(PA - PB).max() <= tol * 1e3 * max(1.0, np.abs(PB).max())
     if dtype == "f64" and c_oracle.available():
         sseO, PO, trO = c_oracle.refine(model, P0, offs, sensor, pts, 12)
         assert np.array_equal(trA[:n, 3], trO[:n, 3]) and relIntr(PA, PO, L) < 1e-7
