@@ -170,6 +170,18 @@ def test_pack_detections_fast_path_and_fallback():
     assert np.array_equal(om, offs) and np.array_equal(mm, m)
 
 
+def test_gather_of_per_view_arrays_equals_the_stacked_matrix(tmp_path):
+    """calib_set_problem_views' staged upload reads the caller's per-view arrays through HostRows::copy
+    (csrc/host_rows.hpp); tests/host_cpp/host_rows_check.cpp holds it, on the host, to the np.vstack of the views
+    (src/calibrate.py:277-282) for every chunking -- borders inside rows and views, empty views."""
+    import subprocess
+    exe = tmp_path / "host_rows_check"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-o", str(exe),
+                    os.path.join(ROOT, "tests", "host_cpp", "host_rows_check.cpp")], check=True, capture_output=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_view_pointers_of_a_detection_list():
     """engine.viewPointers (csrc/fastpack.c): per-view row counts and data addresses of the reference's allDetections
     list, for calib_set_problem_views to gather from -- or None (numpy stacks instead) when a view is not a C-contiguous
