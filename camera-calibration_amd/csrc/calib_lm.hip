@@ -571,7 +571,7 @@ int64_t numParams(const calib_handle_s* h) { return h->L + 6 * h->M; }
 // ============================================================================ C-ABI
 extern "C" {
 
-int calib_version(void) { return 300; }   // 3.0: stream form of the fused kernel
+int calib_version(void) { return 400; }   // 4.0: 768-byte records, calib_set_problem_views, one-lane-per-view update kernel
 
 const char* calib_last_error(void) { return g_err.c_str(); }
 
